@@ -1,0 +1,242 @@
+"""ORACLE — test infrastructure only.  Never imported by ``prism_amd``.
+
+torch-CPU fp32 restatement of the reference's TD-update arithmetic, written functionally over a
+``{state_dict key: tensor}`` mapping (keys as in SURVEY.md Appendix B).  Gradients come from
+autograd, so this is independent of the hand-derived backward in the HIP kernels.  Pinned against
+golden vectors captured from the live reference (tools/gen_golden.py -> tests/golden/update_*.npz,
+checked by tests/test_oracle_golden.py).
+
+Follows (paths under /root/reference):
+  prism/agents/models/minatar_cnn_model.py:14-16,43-46   conv embed
+  prism/agents/models/iqn_model.py:48-93                 IQN forward
+  prism/agents/models/iqn_model.py:95-201                IQN target + quantile-Huber loss
+  prism/agents/models/ffnn_model.py:61-81                LN/Linear/act stack
+  prism/agents/models/q_ensemble.py:44-92                Q-ensemble / DQN loss (always MSE:
+                                                         prism/factory/model_factory.py:39-46)
+  prism/agents/models/composite_model.py:94-144          batch unpack, td errors
+  prism/agents/agent.py:53-79                            loss reduce, clip, optimizer step
+  prism/factory/agent_factory.py:44-47                   Adam flags
+Taus are explicit inputs, in the reference's draw order (iqn_model.py:104,112-126):
+current -> online-next (no target, or double-Q) -> target-next (target present).
+"""
+from dataclasses import dataclass
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class ModelSpec:
+    in_channels: int = 4
+    n_actions: int = 6
+    use_iqn: bool = True
+    use_layer_norm: bool = True
+    n_basis: int = 64
+    iqn_layers: int = 1           # iqn_quantile_model_layers
+    n_tau: int = 8                # current-state quantile samples
+    n_tau_next: int = 8
+    huber_k: float = 1.0
+    dist_loss_weight: float = 1.0
+    propagate_grad: bool = True
+    n_heads: int = 0              # 0: no q model; 1: DQN; 10: IDS ensemble
+    head_layers: int = 0          # ids_n_q_head_model_layers / dqn_n_model_layers
+    q_loss_weight: float = 1.0
+    theil_coef: float = 0.0       # ids_ensemble_variation_coef (0 for DQN)
+    double_q: bool = False
+    max_grad_norm: float = 10.0
+    lr: float = 2.5e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1.5e-4
+
+
+def conv_embed(p, obs):
+    """(B,10,10,C) -> (B,1024), channel-major flatten."""
+    x = obs.permute(0, 3, 1, 2).float()
+    y = F.relu(F.conv2d(x, p["embedding_model.model.0.weight"], p["embedding_model.model.0.bias"]))
+    return y.flatten(1)
+
+
+def _stack(p, prefix, x, n_layers, use_ln, ln_first, final_act):
+    """FFNNModel (ffnn_model.py:61-76): [LN] Linear [ReLU] ... ; indices advance as in nn.Sequential."""
+    idx = 0
+    for i in range(n_layers):
+        if use_ln and (i != 0 or ln_first):
+            x = F.layer_norm(x, (x.shape[-1],), p[f"{prefix}.{idx}.weight"], p[f"{prefix}.{idx}.bias"], 1e-5)
+            idx += 1
+        x = F.linear(x, p[f"{prefix}.{idx}.weight"], p[f"{prefix}.{idx}.bias"])
+        idx += 1
+        if i != n_layers - 1:
+            x = F.relu(x)
+            idx += 1
+    if final_act:
+        x = F.relu(x)
+    return x
+
+
+def iqn_forward(p, spec, e, taus):
+    """e (B,E); taus (T*B,1) -> Z (T*B, A).  Rows are tau-major: row = t*B + b."""
+    B = e.shape[0]
+    T = taus.shape[0] // B
+    if not spec.propagate_grad:
+        e = e.detach()
+    basis = torch.arange(1, spec.n_basis + 1, 1)
+    c = torch.cos(torch.tile(taus, [1, spec.n_basis]) * basis * np.pi)
+    phi = F.relu(F.linear(c, p["distribution_model.phi.0.weight"], p["distribution_model.phi.0.bias"]))
+    h = phi * torch.tile(e, [T, 1])
+    if spec.iqn_layers > 0:
+        h = _stack(p, "distribution_model.model.model", h, spec.iqn_layers, spec.use_layer_norm, True, True)
+    if spec.use_layer_norm:
+        h = F.layer_norm(h, (h.shape[-1],), p["distribution_model.embedding_to_quantile_layer.0.weight"],
+                         p["distribution_model.embedding_to_quantile_layer.0.bias"], 1e-5)
+        z = F.linear(h, p["distribution_model.embedding_to_quantile_layer.1.weight"],
+                     p["distribution_model.embedding_to_quantile_layer.1.bias"])
+    else:
+        z = F.linear(h, p["distribution_model.embedding_to_quantile_layer.weight"],
+                     p["distribution_model.embedding_to_quantile_layer.bias"])
+    return z
+
+
+def iqn_loss(p, p_tgt, spec, e_cur, e_next, acts, returns, dg, taus):
+    """Returns per-sample quantile-Huber loss (B,).  taus: list in draw order."""
+    B = acts.shape[0]
+    T, Tn, k = spec.n_tau, spec.n_tau_next, spec.huber_k
+    taus = list(taus)
+    tau_cur = taus.pop(0)
+    z_cur = iqn_forward(p, spec, e_cur, tau_cur)
+    with torch.no_grad():
+        if p_tgt is None:
+            z_on = iqn_forward(p, spec, e_next, taus.pop(0))
+            z_tg = z_on
+        elif spec.double_q:
+            z_on = iqn_forward(p, spec, e_next, taus.pop(0))
+            z_tg = iqn_forward(p_tgt, spec, e_next, taus.pop(0))
+        else:
+            z_tg = iqn_forward(p_tgt, spec, e_next, taus.pop(0))
+            z_on = z_tg
+        a_star = z_on.view(Tn, B, -1).mean(dim=0).argmax(dim=-1).view(-1, 1)
+        zsel = torch.gather(z_tg, 1, torch.tile(a_star, [Tn, 1]))
+        y = torch.tile(returns.view(-1, 1), [Tn, 1]) + zsel * torch.tile(dg.view(-1, 1), [Tn, 1])
+        y = y.view(Tn, B, 1).transpose(1, 0)                         # (B, T', 1)
+    q = torch.gather(z_cur, 1, torch.tile(acts.view(-1, 1), [T, 1])).view(T, B, 1).transpose(1, 0)
+    delta = y[:, :, None] - q[:, None, :]                             # (B, T', T, 1)
+    le = torch.le(delta.abs(), k).float()
+    hub = le * 0.5 * delta.square() + (1 - le) * k * (delta.abs() - 0.5 * k)
+    tq = tau_cur.view(T, B, 1).transpose(1, 0)
+    tq = torch.tile(tq[:, None, :, :], [1, Tn, 1, 1]).float()
+    ind = torch.where(delta < 0, 1, 0).float().detach()
+    rho = (torch.abs(tq - ind) * hub) / k
+    return rho.sum(dim=2).mean(dim=1).view(-1) * spec.dist_loss_weight
+
+
+def qens_forward(p, spec, e):
+    """(B,E) -> (B, A, n_heads)."""
+    outs = []
+    for h in range(spec.n_heads):
+        if spec.head_layers > 0:
+            outs.append(_stack(p, f"q_function_model.q_heads.{h}.model", e, spec.head_layers,
+                               spec.use_layer_norm, True, False))
+        elif spec.use_layer_norm:
+            x = F.layer_norm(e, (e.shape[-1],), p[f"q_function_model.q_heads.{h}.0.weight"],
+                             p[f"q_function_model.q_heads.{h}.0.bias"], 1e-5)
+            outs.append(F.linear(x, p[f"q_function_model.q_heads.{h}.1.weight"],
+                                 p[f"q_function_model.q_heads.{h}.1.bias"]))
+        else:
+            outs.append(F.linear(e, p[f"q_function_model.q_heads.{h}.weight"],
+                                 p[f"q_function_model.q_heads.{h}.bias"]))
+    return torch.stack(outs, dim=-1)
+
+
+def qens_loss(p, p_tgt, spec, e_cur, e_next, acts, returns, dg):
+    B = acts.shape[0]
+    ar = torch.arange(B)
+    q_cur = qens_forward(p, spec, e_cur)
+    with torch.no_grad():
+        if p_tgt is None:
+            q_on = q_tg = qens_forward(p, spec, e_next)
+        elif spec.double_q:
+            q_on = qens_forward(p, spec, e_next)
+            q_tg = qens_forward(p_tgt, spec, e_next)
+        else:
+            q_tg = q_on = qens_forward(p_tgt, spec, e_next)
+        best = q_on.argmax(dim=-2)                                    # (B, heads)
+        nxt = q_tg[ar[:, None], best, torch.arange(spec.n_heads)[None, :]]
+        target = returns.view(-1, 1) + nxt * dg.view(-1, 1)
+    ql = F.mse_loss(q_cur[ar, acts, :], target, reduction="none").mean(dim=-1)
+    theil = torch.tensor(0.0)
+    if spec.theil_coef != 0:
+        l2 = torch.stack([torch.cat([p[k].reshape(-1) for k in _head_keys(p, h)]).norm()
+                          for h in range(spec.n_heads)])
+        ratio = l2 / l2.mean()
+        theil = (ratio * torch.log(ratio)).mean()
+    return spec.q_loss_weight * (ql - theil * spec.theil_coef), theil
+
+
+def _head_keys(p, h):
+    pre = f"q_function_model.q_heads.{h}."
+    return [k for k in p.keys() if k.startswith(pre)]
+
+
+def composite_losses(p, p_tgt, spec, batch, taus):
+    """batch: dict(obs (B,10,10,C), next_obs, reward (B,), nonterminal (B,) bool, gamma (B,), action (B,))."""
+    obs, nobs = batch["obs"], batch["next_obs"]
+    R = batch["reward"].flatten()
+    dg = batch["gamma"].flatten().float() * batch["nonterminal"].flatten().float()
+    acts = batch["action"].flatten().long()
+    e_cur = conv_embed(p, obs)
+    with torch.no_grad():
+        e_next = conv_embed(p_tgt if p_tgt is not None else p, nobs)
+    dl = ql = td = None
+    aux = {}
+    if spec.use_iqn:
+        dl = iqn_loss(p, p_tgt, spec, e_cur, e_next, acts, R, dg, taus)
+    if spec.n_heads > 0:
+        ql, aux["theil"] = qens_loss(p, p_tgt, spec, e_cur, e_next, acts, R, dg)
+    if dl is not None and ql is not None:
+        td = dl.detach() * 0.5 + ql.detach() * 0.5
+    elif dl is not None:
+        td = dl.detach()
+    elif ql is not None:
+        td = ql.abs().detach()
+    return dl, ql, td, aux
+
+
+class LearnerOracle:
+    """Holds leaf parameter tensors + torch.optim.Adam; one call == Agent._update_without_cuda_graph."""
+
+    def __init__(self, state_dict, spec, target_state_dict=None):
+        self.spec = spec
+        self.p = {k: v.detach().clone().float().requires_grad_(True) for k, v in state_dict.items()}
+        self.p_tgt = None
+        if target_state_dict is not None:
+            self.p_tgt = {k: v.detach().clone().float() for k, v in target_state_dict.items()}
+        self.opt = torch.optim.Adam(list(self.p.values()), lr=spec.lr, betas=(spec.beta1, spec.beta2),
+                                    eps=spec.adam_eps)
+        self.last = {}
+
+    def update(self, batch, per_weights, taus, apply=True):
+        dl, ql, td, aux = composite_losses(self.p, self.p_tgt, self.spec, batch, taus)
+        total = 0
+        if dl is not None:
+            total = total + (dl * per_weights).mean()
+        if ql is not None:
+            total = total + (ql * per_weights).mean()
+        self.opt.zero_grad()
+        total.backward()
+        grads = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v))
+                 for k, v in self.p.items()}
+        gnorm = torch.nn.utils.clip_grad_norm_(list(self.p.values()), self.spec.max_grad_norm)
+        if apply:
+            self.opt.step()
+        self.last = dict(dl=None if dl is None else dl.detach(), ql=None if ql is None else ql.detach(),
+                         td=td, total=total.detach(), grads=grads, grad_norm=gnorm.detach(), **aux)
+        return td
+
+    def sync_target(self):
+        for k in self.p_tgt:
+            self.p_tgt[k].copy_(self.p[k].detach())
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}

@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference (imported from /root/reference).
+
+Build-container only: the reference does not exist on the GPU box, and nothing in tests/ or the
+product imports it.  The fixtures hold DATA only — seeds, inputs, captured quantile samples and the
+reference's outputs — never reference source.
+
+    python tools/gen_golden.py            # writes tests/golden/{update_*,nstep_*}.npz
+
+What is captured:
+  update_<case>.npz  Agent.update() (non-graph path, prism/agents/agent.py:53-79) for N steps on
+                     seeded synthetic MinAtar-shaped batches: inputs, taus (torch.rand patched to
+                     record, order current -> next -> [target]), per-sample losses / td errors,
+                     total loss, per-tensor grad L2 norms, global grad norm, per-tensor parameter
+                     checksums after every step (+ full tensors for the small cases).
+  nstep_chain.npz    TimestepBuffer._compute_n_step / _timesteps_to_batch
+                     (prism/experience/timestep_buffer.py:79-238) on hand-built Timestep chains.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.dont_write_bytecode = True
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    # stand-ins for absent third-party modules the experience half imports at module scope
+    td = types.ModuleType("tensordict")
+
+    class TensorDict(dict):
+        def __init__(self, d=None, batch_size=None, device=None):
+            super().__init__(d or {})
+            self.batch_size, self.device = batch_size, device
+
+    td.TensorDict = TensorDict
+    sys.modules["tensordict"] = td
+    sys.modules["wandb"] = types.ModuleType("wandb")
+
+
+def synth_batch(rng, B, C=4, A=6, p_term=0.05):
+    obs = (rng.random((B, 1, 10, 10, C)) < 0.1).astype(np.float32)
+    nobs = (rng.random((B, 1, 10, 10, C)) < 0.1).astype(np.float32)
+    rew = rng.standard_normal((B, 1)).astype(np.float32)
+    nonterm = rng.random((B, 1)) >= p_term
+    g = np.full((B, 1), 0.99 ** 3, np.float32)
+    sel = rng.random(B)
+    g[sel < 0.05, 0] = np.float32(0.99 ** 2)
+    g[sel < 0.025, 0] = np.float32(0.99)
+    act = rng.integers(0, A, size=(B, 1)).astype(np.int64)
+    w = (rng.random(B).astype(np.float32) * 0.9 + 0.1)
+    return dict(obs=obs, next_obs=nobs, reward=rew, nonterminal=nonterm, gamma=g, action=act, w=w)
+
+
+def to_ref_batch(b):
+    t = torch.from_numpy
+    return {"observation": t(b["obs"]), "next": {"observation": t(b["next_obs"]), "reward": t(b["reward"])},
+            "nonterminal": t(b["nonterminal"]), "gamma": t(b["gamma"]), "action": t(b["action"])}
+
+
+def tensor_stats(sd):
+    names = list(sd.keys())
+    s = np.array([float(sd[k].double().sum()) for k in names])
+    l2 = np.array([float(sd[k].double().norm()) for k in names])
+    return names, s, l2
+
+
+CASES = {
+    # name: (config overrides, B, steps, store_full_params)
+    "iqn_small": (dict(use_ids=False, use_iqn=True, use_dqn=False, iqn_n_current_state_quantile_samples=4,
+                       iqn_n_next_state_quantile_samples=4), 8, 3, True),
+    "iqn_c3": (dict(use_ids=False, use_iqn=True, use_dqn=False), 256, 3, False),
+    "dqn_c2": (dict(use_ids=False, use_iqn=False, use_dqn=True, use_layer_norm=False), 256, 3, True),
+    "dqn_ln": (dict(use_ids=False, use_iqn=False, use_dqn=True, use_layer_norm=True), 32, 2, False),
+    "dqn_target_c2": (dict(use_ids=False, use_iqn=False, use_dqn=True, use_layer_norm=False,
+                           use_target_network=True), 64, 2, False),
+    "full_c4": (dict(use_ids=True, use_iqn=True, use_target_network=True), 512, 2, False),
+    "full_small": (dict(use_ids=True, use_iqn=True, use_target_network=True), 16, 2, False),
+    "full_notarget": (dict(use_ids=True, use_iqn=True, use_target_network=False), 16, 2, False),
+    "full_doubleq": (dict(use_ids=True, use_iqn=True, use_target_network=True, use_double_q_learning=True),
+                     16, 2, False),
+    "iqn_target": (dict(use_ids=False, use_iqn=True, use_target_network=True), 32, 2, False),
+    "iqn_doubleq": (dict(use_ids=False, use_iqn=True, use_target_network=True, use_double_q_learning=True),
+                    32, 2, False),
+    "iqn_tau32": (dict(use_ids=False, use_iqn=True, iqn_n_current_state_quantile_samples=32,
+                       iqn_n_next_state_quantile_samples=32), 16, 2, False),
+}
+
+
+def gen_update_case(name, overrides, B, steps, store_full):
+    from prism.config import Config, MINATAR_CONFIG
+    from prism.factory import agent_factory
+
+    cfg = Config(**MINATAR_CONFIG.__dict__)
+    cfg.device, cfg.use_cuda_graph, cfg.use_e_greedy = "cpu", False, False
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    C, A = 4, 6
+    torch.manual_seed(cfg.seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = agent_factory.build_agent(cfg, (10, 10, C), A)
+    out = {"seed": cfg.seed, "B": B, "steps": steps, "C": C, "A": A}
+    out["overrides_keys"] = np.array(list(overrides.keys()))
+    out["overrides_vals"] = np.array([repr(v) for v in overrides.values()])
+    names, s0, l0 = tensor_stats(agent.model.state_dict())
+    out["param_names"] = np.array(names)
+    out["init_sum"], out["init_l2"] = s0, l0
+    out["n_params"] = sum(p.numel() for p in agent.model.parameters())
+    if store_full:
+        for k, v in agent.model.state_dict().items():
+            out["init/" + k] = v.numpy().copy()
+
+    rng = np.random.default_rng(1000 + sum(map(ord, name)))
+    real_rand = torch.rand
+    for step in range(steps):
+        b = synth_batch(rng, B, C, A)
+        taus = []
+
+        def rec(*a, **k):
+            r = real_rand(*a, **k)
+            taus.append(r.clone())
+            return r
+
+        torch.rand = rec
+        try:
+            td = agent.update(to_ref_batch(b), per_weights=torch.from_numpy(b["w"]))
+        finally:
+            torch.rand = real_rand
+        pre = f"s{step}/"
+        out[pre + "obs_bits"] = np.packbits(b["obs"].astype(np.uint8).reshape(-1))
+        out[pre + "next_obs_bits"] = np.packbits(b["next_obs"].astype(np.uint8).reshape(-1))
+        for k in ("reward", "nonterminal", "gamma", "action", "w"):
+            out[pre + k] = b[k]
+        out[pre + "n_taus"] = len(taus)
+        for i, t in enumerate(taus):
+            out[pre + f"tau{i}"] = t.numpy().reshape(-1)
+        out[pre + "td"] = td.detach().numpy()
+        if agent._static_distribution_loss is not None:
+            out[pre + "dl"] = agent._static_distribution_loss.detach().numpy()
+        if agent._static_q_loss is not None:
+            out[pre + "ql"] = agent._static_q_loss.detach().numpy()
+        out[pre + "total"] = float(agent._static_total_loss.detach())
+        # grads left on the parameters are the CLIPPED ones; recover the global norm from the
+        # reference's own arithmetic: clip multiplies by min(1, max/(norm+1e-6))
+        gl2 = np.array([float(p.grad.double().norm()) if p.grad is not None else 0.0
+                        for p in agent.model.parameters()])
+        out[pre + "clipped_grad_l2"] = gl2
+        n2, s, l2 = tensor_stats(agent.model.state_dict())
+        out[pre + "post_sum"], out[pre + "post_l2"] = s, l2
+        if agent.model.q_function_model is not None:
+            out[pre + "theil"] = float(agent.model.q_function_model.theil.detach())
+        if store_full and step == steps - 1:
+            for k, v in agent.model.state_dict().items():
+                out[pre + "post/" + k] = v.numpy().copy()
+        if store_full and step == 0:
+            for (k, p) in agent.model.named_parameters():
+                out[pre + "clipped_grad/" + k] = p.grad.numpy().copy()
+        if cfg.use_target_network and step == 0:
+            agent.sync_target_model()       # exercise hard sync between steps
+    np.savez_compressed(os.path.join(OUT, f"update_{name}.npz"), **out)
+    print(f"update_{name}: P={out['n_params']} total[-1]={out[pre + 'total']:.6f}")
+
+
+def gen_nstep():
+    """Hand-built Timestep chains pushed through the reference's n-step + collate."""
+    from prism.experience import Timestep, TimestepBuffer
+    import weakref
+
+    class FakeRB:
+        _batch_size = 0
+
+    rng = np.random.default_rng(7)
+    n_step, gamma = 3, 0.99
+    keep = []            # strong refs (links are weak)
+    rows = []            # per stored timestep: dict of scalars
+    env_streams = 3
+    O = (10, 10, 4)
+    next_id = [0]
+
+    def new_ts():
+        t = Timestep(id=next_id[0])
+        next_id[0] += 1
+        return t
+
+    # interleave several env streams, as the collector does (experience_collector.py:94-120)
+    current = []
+    for e in range(env_streams):
+        t = new_ts()
+        t.obs = torch.from_numpy((rng.random(O) < 0.1).astype(np.float32))
+        current.append(t)
+    stored = []          # completed timesteps in insertion order
+    steps_per_stream = [0] * env_streams
+    for it in range(67):
+        e = it % env_streams
+        cur = current[e]
+        steps_per_stream[e] += 1
+        k = steps_per_stream[e]
+        done = (k % 7 == 0)
+        trunc = (not done) and (k % 5 == 0)
+        cur.action = int(rng.integers(0, 6))
+        cur.reward = float(np.float32(rng.standard_normal()))
+        cur.done, cur.truncated = bool(done), bool(trunc)
+        nxt = new_ts()
+        nxt.obs = torch.from_numpy((rng.random(O) < 0.1).astype(np.float32))
+        if trunc:
+            tr = new_ts()
+            tr.obs = torch.from_numpy((rng.random(O) < 0.1).astype(np.float32))
+            tr.prev = weakref.ref(cur)
+            cur.next = tr
+        elif not done:
+            nxt.prev = weakref.ref(cur)
+            cur.next = weakref.ref(nxt)
+        current[e] = nxt
+        stored.append(cur)
+        keep.append(cur)
+    keep.extend(current)
+
+    buf = TimestepBuffer(FakeRB(), frame_stack=1, device="cpu", n_step=n_step, gamma=gamma)
+    N = len(stored)
+    batch = buf._timesteps_to_batch(stored, N)
+    id_to_row = {t.id: i for i, t in enumerate(stored)}
+    out = {"n_step": n_step, "gamma": gamma, "N": N}
+    out["obs"] = np.stack([t.obs.numpy() for t in stored])
+    succ = np.zeros_like(out["obs"])
+    link = np.full(N, -1, np.int32)
+    has_next = np.zeros(N, bool)
+    for i, t in enumerate(stored):
+        nx = t.next
+        if nx is None:
+            continue
+        node = nx if isinstance(nx, Timestep) else nx()
+        has_next[i] = True
+        succ[i] = node.obs.numpy()
+        if not isinstance(nx, Timestep) and node.reward is not None and node.id in id_to_row:
+            link[i] = id_to_row[node.id]
+    out["succ_obs"], out["link"], out["has_next"] = succ, link, has_next
+    out["reward"] = np.array([t.reward for t in stored], np.float64)
+    out["done"] = np.array([t.done for t in stored])
+    out["truncated"] = np.array([t.truncated for t in stored])
+    out["action"] = np.array([t.action for t in stored], np.int64)
+    out["exp_n_step_return"] = np.array([t.n_step_return for t in stored], np.float64)
+    out["exp_n_step_gamma"] = np.array([t.n_step_gamma for t in stored], np.float64)
+    out["exp_n_step_done"] = np.array([bool(t.n_step_done) for t in stored])
+    out["exp_needs_n_step"] = np.array([bool(t.needs_n_step) for t in stored])
+    out["exp_batch_obs"] = batch["observation"].numpy()
+    out["exp_batch_next_obs"] = batch["next"]["observation"].numpy()
+    out["exp_batch_reward"] = batch["next"]["reward"].numpy()
+    out["exp_batch_nonterminal"] = batch["nonterminal"].numpy()
+    out["exp_batch_gamma"] = batch["gamma"].numpy()
+    out["exp_batch_action"] = batch["action"].numpy()
+    np.savez_compressed(os.path.join(OUT, "nstep_chain.npz"), **out)
+    print("nstep_chain:", N, "timesteps; needs_n_step:", int(out["exp_needs_n_step"].sum()),
+          "terminal rows:", int((~out["exp_batch_nonterminal"]).sum()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _import_reference()
+    which = sys.argv[1:] or (list(CASES) + ["nstep"])
+    for name in which:
+        if name == "nstep":
+            gen_nstep()
+        else:
+            gen_update_case(name, *CASES[name])
+
+
+if __name__ == "__main__":
+    main()
