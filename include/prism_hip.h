@@ -1,0 +1,241 @@
+/*
+ * prism_hip.h — C ABI of libprism_hip.so (gfx950 / MI355X).
+ *
+ * The reference (AechPro/Prism) has no FFI layer: its hot path is Python calling torch + the
+ * third-party torchrl segment trees.  These entry points are what a binding for that path would
+ * call; each one names the reference interface it replaces (paths under /root/reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless
+ *     the parameter says "host";
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising; no hidden allocation, no hidden sync — safe to capture into a hipGraph;
+ *   - return value: PRISM_OK or a negative PRISM_ERR_* code; prism_last_error() returns a
+ *     thread-local message; nothing throws across the boundary;
+ *   - single-threaded caller per stream, as the reference's learner loop
+ *     (prism/learner.py:75-143).
+ */
+#ifndef PRISM_HIP_H
+#define PRISM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRISM_ABI_VERSION 1
+
+#define PRISM_OK 0
+#define PRISM_ERR_INVALID (-1)     /* bad argument / shape the kernels do not cover          */
+#define PRISM_ERR_HIP (-2)         /* a HIP runtime call failed                             */
+#define PRISM_ERR_UNSUPPORTED (-3) /* valid reference configuration not implemented here    */
+
+#define PRISM_MAX_NSTEP 15
+
+/* per-slot flag bits of the replay ring */
+#define PRISM_FLAG_DONE 1u      /* Timestep.done                                            */
+#define PRISM_FLAG_TRUNC 2u     /* Timestep.truncated                                       */
+#define PRISM_FLAG_HAS_NEXT 4u  /* Timestep.next is not None                                */
+
+/* device status word bits (prism_replay_desc.status) */
+#define PRISM_STATUS_NONPOSITIVE_PSUM 1
+#define PRISM_STATUS_NONPOSITIVE_PMIN 2
+
+typedef void *prism_stream_t;
+
+const char *prism_last_error(void);
+int prism_abi_version(void);
+/* host out-params; multiprocessor count and gcnArch name ("gfx950") of `device`. */
+int prism_device_info(int device, int *cu_count, char *arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------
+ * Replay ring + prioritized sum/min trees, resident in HBM.
+ *
+ * Replaces torchrl PrioritizedReplayBuffer(ListStorage) + prism TimestepBuffer
+ * (prism/factory/exp_buffer_factory.py:22-33, prism/experience/timestep_buffer.py:10-238).
+ * Layout: structure-of-arrays ring of `capacity` slots; trees are binary segment trees with
+ * `tree_capacity` = smallest power of two STRICTLY greater than `capacity`, 2*tree_capacity fp32
+ * nodes each, leaf i at node (i | tree_capacity), root at node 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct prism_replay_desc {
+    int64_t capacity;
+    int64_t tree_capacity;
+    int32_t obs_elems;   /* floats per observation (10*10*C for MinAtar)                      */
+    int32_t n_step;      /* n-step return length, 1..PRISM_MAX_NSTEP                          */
+    float *obs;          /* [capacity][obs_elems]                                             */
+    float *succ_obs;     /* [capacity][obs_elems] observation of the slot's immediate successor */
+    float *reward;       /* [capacity]                                                        */
+    int32_t *action;     /* [capacity]                                                        */
+    uint8_t *flags;      /* [capacity] PRISM_FLAG_*                                           */
+    int32_t *link;       /* [capacity] ring slot of the stored successor, -1 if none yet      */
+    int32_t *back;       /* [capacity] ring slot of the predecessor that links here, or -1    */
+    float *sum_tree;     /* [2*tree_capacity] or NULL for uniform replay                      */
+    float *min_tree;     /* [2*tree_capacity] or NULL                                         */
+    float *per_state;    /* [4] {running max raw priority, last p_sum, last p_min, unused}    */
+    int32_t *status;     /* [1] sticky PRISM_STATUS_* bits                                    */
+    double gammas[PRISM_MAX_NSTEP + 1]; /* gamma**k as Python float64 (timestep_buffer.py:17)  */
+} prism_replay_desc;
+
+/* trees := identity (0 / FLT_MAX), per_state := {1,0,0,0}, status := 0, link/back := -1.
+ * torchrl PrioritizedSampler._init. */
+int prism_replay_init(const prism_replay_desc *rp, prism_stream_t stream);
+
+/* TimestepBuffer.extend (timestep_buffer.py:32-33) for n completed timesteps, applied in order
+ * i = 0..n-1: overwrite ring slot slots[i] (detaching any predecessor that linked to the old row),
+ * store the row, link prev_slot[i] -> slots[i] when prev_slot[i] >= 0, and give the slot the
+ * sampler's default priority (max_priority + eps) ** alpha in both trees
+ * (torchrl PrioritizedSampler.extend).  All array arguments are device staging buffers. */
+int prism_replay_insert(const prism_replay_desc *rp, int32_t n, const int32_t *slots,
+                        const float *obs, const float *succ_obs, const float *reward,
+                        const int32_t *action, const uint8_t *flags, const int32_t *prev_slot,
+                        float alpha, float eps, prism_stream_t stream);
+
+/* PrioritizedSampler.sample (called at timestep_buffer.py:37): p_sum/p_min = query(0,size);
+ * index[i] = min(scan_lower_bound(mass[i]), size-1); weight[i] = (leaf/p_min) ** -beta.
+ * mass == NULL: masses are drawn on the device, U(0,p_sum) in float64 narrowed to fp32, from
+ * Philox4x32-10 keyed by (seed, offset); else `mass` holds `batch` fp32 values (parity mode: the
+ * reference draws them with NumPy's global RNG, which cannot be reproduced on the device).
+ * `size` = number of stored items (len(storage)).  Indices are int64 as in torchrl. */
+int prism_per_sample(const prism_replay_desc *rp, int64_t size, int32_t batch, const float *mass,
+                     uint64_t seed, uint64_t offset, float beta, int64_t *out_index,
+                     float *out_weight, prism_stream_t stream);
+
+/* torchrl RandomSampler (uniform replay, exp_buffer_factory.py:30-33): index ~ U{0..size-1}. */
+int prism_uniform_sample(int64_t size, int32_t batch, uint64_t seed, uint64_t offset,
+                         int64_t *out_index, prism_stream_t stream);
+
+/* _compute_n_step + _timesteps_to_batch (timestep_buffer.py:79-238) for the sampled slots:
+ * walks <= n_step links per sample (fp64 accumulate, fp32 store) and gathers rows.
+ * out_nonterminal is torch.bool storage (1 byte), out_action int64. */
+int prism_replay_gather(const prism_replay_desc *rp, const int64_t *index, int32_t batch,
+                        float *out_obs, float *out_next_obs, float *out_reward,
+                        uint8_t *out_nonterminal, float *out_gamma, int64_t *out_action,
+                        prism_stream_t stream);
+
+/* PrioritizedSampler.update_priority (timestep_buffer.py:53-54 <- learner.py:120):
+ * max_priority = max(max_priority, max(priority)); leaf = (priority + eps) ** alpha in both
+ * trees; duplicate indices resolve as the sequential loop would (last occurrence wins); every
+ * ancestor is recomputed as op(left, right).  take_abs != 0 applies |.| first (learner.py:120
+ * passes new_per_weights.abs()). */
+int prism_per_update(const prism_replay_desc *rp, const int64_t *index, const float *priority,
+                     int32_t batch, float alpha, float eps, int32_t take_abs,
+                     prism_stream_t stream);
+
+/* Recompute every internal node from the leaves (after the caller wrote leaves in bulk: restoring a
+ * saved sampler, torchrl PrioritizedSampler.loads, or a synthetic pre-fill). */
+int prism_per_rebuild(const prism_replay_desc *rp, prism_stream_t stream);
+
+/* out[0] = sum_tree.query(0,size), out[1] = min_tree.query(0,size) (device floats). */
+int prism_per_query(const prism_replay_desc *rp, int64_t size, float *out2, prism_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * TD update: CompositeModel.get_losses + Agent._update_without_cuda_graph
+ * (prism/agents/models/composite_model.py:94-144, iqn_model.py:48-201, q_ensemble.py:44-92,
+ *  prism/agents/agent.py:53-79), fp32 throughout.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct prism_model_dims {
+    int32_t in_channels;   /* C; observations are (10,10,C) NHWC                              */
+    int32_t n_actions;     /* A <= 16                                                         */
+    int32_t embed_dim;     /* 1024 = 16*8*8 (minatar_cnn_model.py:14)                         */
+    int32_t use_iqn;
+    int32_t n_basis;       /* 64                                                              */
+    int32_t iqn_layers;    /* iqn_quantile_model_layers (1)                                   */
+    int32_t iqn_width;     /* iqn_quantile_model_feature_dim (128)                            */
+    int32_t n_tau;         /* current-state quantile samples T                                */
+    int32_t n_tau_next;    /* next-state quantile samples T'                                  */
+    int32_t use_layer_norm;
+    int32_t n_heads;       /* 0 none, 1 DQN, >1 IDS ensemble                                  */
+    int32_t head_layers;   /* linear layers per head (1 or 2)                                 */
+    int32_t head_width;    /* hidden width of a 2-layer head (128)                            */
+    int32_t has_target;    /* target network present                                          */
+    int32_t double_q;
+    int32_t propagate_grad; /* IQN gradients reach the embedding (model_factory.py:87)        */
+    float huber_k;
+    float dist_loss_weight;
+    float q_loss_weight;
+    float theil_coef;      /* ids_ensemble_variation_coef                                     */
+} prism_model_dims;
+
+/* Offsets (in floats) of each tensor inside the flat parameter buffer, which is laid out in
+ * model.parameters() order.  -1 = tensor absent. */
+typedef struct prism_param_offsets {
+    int64_t n_params;
+    int64_t conv_w, conv_b;
+    int64_t phi_w, phi_b;
+    int64_t iqn_ln1_g, iqn_ln1_b, iqn_w1, iqn_b1;
+    int64_t iqn_ln2_g, iqn_ln2_b, iqn_w2, iqn_b2;
+    int64_t head_base;    /* first float of head 0                                           */
+    int64_t head_stride;  /* floats per head                                                 */
+    int64_t h_ln1_g, h_ln1_b, h_w1, h_b1; /* relative to the head's base                     */
+    int64_t h_ln2_g, h_ln2_b, h_w2, h_b2; /* (1-layer head: only h_ln1_* (if LN) and h_w1/h_b1) */
+} prism_param_offsets;
+
+typedef struct prism_adam_hyper {
+    float lr, beta1, beta2, eps;
+    float max_grad_norm;
+    float grad_scale;      /* multiplied into the gradient before the norm (1/world_size)    */
+} prism_adam_hyper;
+
+typedef struct prism_learner_desc {
+    prism_model_dims dims;
+    prism_param_offsets off;
+    int32_t batch;            /* B                                                           */
+    int32_t reserved0;
+    /* parameters and optimizer state, flat fp32 [n_params] */
+    float *params;
+    const float *target_params; /* NULL when !has_target                                     */
+    float *grads;             /* out: dL/dparams (unclipped, unscaled)                        */
+    float *adam_m;
+    float *adam_v;
+    int64_t *adam_step;       /* [1] device step counter, incremented by prism_learner_clip_adam */
+    /* minibatch (the static batch of timestep_buffer.py:84-104) */
+    const float *obs;         /* [B][10][10][C]                                               */
+    const float *next_obs;
+    const float *reward;      /* [B] n-step return                                            */
+    const uint8_t *nonterminal; /* [B] torch.bool                                            */
+    const float *gamma;       /* [B] gamma ** m                                               */
+    const int64_t *action;    /* [B]                                                          */
+    const float *per_weights; /* [B] or NULL (== 1, learner.py:109)                           */
+    /* quantile samples, tau-major rows (row = t*B + b, iqn_model.py:70).  NULL => drawn in-kernel
+     * from Philox(seed, offset) and written to tau_out. */
+    const float *tau_cur;     /* [T*B]                                                        */
+    const float *tau_next_online; /* [T'*B] used when !has_target or double_q                 */
+    const float *tau_next_target; /* [T'*B] used when has_target                              */
+    float *tau_out;           /* [3][max(T,T')*B] or NULL                                     */
+    uint64_t seed, offset;
+    /* outputs */
+    float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */
+    float *out_q_loss;        /* [B] or NULL  (Agent._static_q_loss)                          */
+    float *out_td;            /* [B]          (td_errors, composite_model.py:135-142)         */
+    float *out_scalars;       /* [8] {total loss, mean dl*w, mean ql*w, grad norm, theil, clip coef, -, -} */
+    float *dbg_z;             /* optional [ (T+T')*B*A ] quantile estimates (tests) or NULL    */
+    void *workspace;          /* >= prism_learner_workspace_bytes()                           */
+    size_t workspace_bytes;
+    prism_adam_hyper hyper;
+} prism_learner_desc;
+
+/* host: bytes of scratch prism_learner_fwd_bwd needs for (dims, batch). 0 on unsupported dims. */
+size_t prism_learner_workspace_bytes(const prism_model_dims *dims, int32_t batch);
+
+/* host: PRISM_OK if the kernels cover this (dims, batch) combination. */
+int prism_learner_supported(const prism_model_dims *dims, int32_t batch);
+
+/* get_losses + backward: fills out_*, grads (complete dL/dparams of
+ * mean(dl*w) + mean(ql*w), agent.py:58-64,71-72) — the RCCL all-reduce of `grads` sits between
+ * this call and prism_learner_clip_adam in data-parallel runs. */
+int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream);
+
+/* clip_grad_norm_(max_grad_norm) + Adam step (agent.py:73-74; torch.optim.Adam defaults,
+ * agent_factory.py:44-47) over the flat buffers; adam_step += 1. */
+int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream);
+
+/* Agent.sync_target_model (agent.py:149-152): target := online (device-to-device copy). */
+int prism_sync_target(float *target_params, const float *params, int64_t n_params,
+                      prism_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRISM_HIP_H */

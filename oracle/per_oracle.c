@@ -38,6 +38,21 @@ typedef struct {
     float *values;     /* 2 * capacity nodes                        */
 } seg_tree;
 
+/* torch.pow with a scalar exponent special-cases 0.5 -> sqrt and -0.5 -> 1/sqrt (ATen
+ * pow_tensor_scalar_optimized_kernel); both are correctly rounded, which is what makes the
+ * default alpha = beta = 0.5 reproducible bit-for-bit on any IEEE machine. */
+static float pow_alpha(float x, float alpha) {
+    if (alpha == 0.5f) return sqrtf(x);
+    if (alpha == 1.0f) return x;
+    return powf(x, alpha);
+}
+static float pow_neg_beta(float x, float beta) {
+    if (beta == 0.5f) return 1.0f / sqrtf(x);
+    if (beta == 1.0f) return 1.0f / x;
+    if (beta == 0.0f) return 1.0f;
+    return powf(x, -beta);
+}
+
 static float seg_op(const seg_tree *t, float a, float b) {
     if (t->is_min) return a < b ? a : b; /* std::min(a, b) */
     return a + b;
@@ -127,7 +142,7 @@ void oracle_per_sample(const seg_tree *sum_t, const seg_tree *min_t, int64_t len
         if (idx > len - 1) idx = len - 1;
         out_index[i] = idx;
         float w = oracle_tree_get(sum_t, idx) / p_min;
-        out_weight[i] = powf(w, -beta);
+        out_weight[i] = pow_neg_beta(w, beta);
     }
 }
 
@@ -136,12 +151,16 @@ void oracle_per_sample(const seg_tree *sum_t, const seg_tree *min_t, int64_t len
  * p = (priority + eps) ** alpha written to both trees, sequentially (last duplicate wins).
  * Returns the new running max.
  */
+float oracle_default_priority(float max_priority, float alpha, float eps) {
+    return pow_alpha(max_priority + eps, alpha);
+}
+
 float oracle_per_update(seg_tree *sum_t, seg_tree *min_t, const int64_t *index, const float *priority,
                         int64_t n, float alpha, float eps, float max_priority) {
     for (int64_t i = 0; i < n; ++i)
         if (priority[i] > max_priority) max_priority = priority[i];
     for (int64_t i = 0; i < n; ++i) {
-        float p = powf(priority[i] + eps, alpha);
+        float p = pow_alpha(priority[i] + eps, alpha);
         oracle_tree_update(sum_t, index[i], p);
         oracle_tree_update(min_t, index[i], p);
     }

@@ -49,6 +49,8 @@ def lib():
         L.oracle_tree_scan_lower_bound.restype = i64
         L.oracle_tree_scan_lower_bound.argtypes = [vp, f32]
         L.oracle_per_sample.argtypes = [vp, vp, i64, vp, i64, f32, vp, vp, vp]
+        L.oracle_default_priority.restype = f32
+        L.oracle_default_priority.argtypes = [f32, f32, f32]
         L.oracle_per_update.restype = f32
         L.oracle_per_update.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32]
         L.oracle_nstep_gather.argtypes = [vp, vp, vp, vp, vp, vp, i64, ctypes.c_int32, vp, vp, i64,
@@ -103,8 +105,8 @@ class PrioritizedSamplerOracle:
 
     @property
     def default_priority(self):
-        # torchrl evaluates this in Python floats: (max + eps) ** alpha
-        return (self.max_priority + self.eps) ** self.alpha
+        # (max + eps) ** alpha, evaluated in fp32 like update_priority's pow (see C header)
+        return lib().oracle_default_priority(self.max_priority, self.alpha, self.eps)
 
     def add(self, index):
         p = np.float32(self.default_priority)
@@ -160,8 +162,7 @@ class ReplayOracle:
         # any slot that linked to the row being overwritten loses its successor
         self.link[self.link == s] = -1
         self.obs[s] = np.asarray(obs, np.float32).reshape(-1)
-        if succ_obs is not None:
-            self.succ_obs[s] = np.asarray(succ_obs, np.float32).reshape(-1)
+        self.succ_obs[s] = 0.0 if succ_obs is None else np.asarray(succ_obs, np.float32).reshape(-1)
         self.reward[s] = reward
         self.action[s] = action
         self.flags[s] = (FLAG_DONE if done else 0) | (FLAG_TRUNC if truncated else 0) | \

@@ -1,0 +1,102 @@
+// Shared host/device helpers for libprism_hip (gfx950 only: wave64, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "prism_hip.h"
+
+namespace prism {
+
+void set_error(const char *fmt, ...);
+
+#define PRISM_CHECK_ARG(cond, msg)                            \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            ::prism::set_error("%s: %s", __func__, msg);      \
+            return PRISM_ERR_INVALID;                         \
+        }                                                     \
+    } while (0)
+
+#define PRISM_CHECK_LAUNCH()                                                        \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ::prism::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return PRISM_ERR_HIP;                                                   \
+        }                                                                           \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// D = A(16x4) * B(4x16) + C, exact fp32 FMA chain.  Lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; D[row = 4*(l>>4) + r][col = l&15] lands in element r.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11), counter-based: no state, reproducible per element ----
+struct Philox {
+    uint32_t k0, k1;
+    __host__ __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t &hi, uint32_t &lo) {
+        uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32);
+        lo = (uint32_t)p;
+    }
+    // counter = (ctr, stream); returns 4 words
+    __host__ __device__ inline void operator()(uint64_t ctr, uint64_t stream, uint32_t out[4]) const {
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)stream,
+                 c3 = (uint32_t)(stream >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0, l0, h1, l1;
+            mulhilo(0xD2511F53u, c0, h0, l0);
+            mulhilo(0xCD9E8D57u, c2, h1, l1);
+            uint32_t n0 = h1 ^ c1 ^ a, n1 = l1, n2 = h0 ^ c3 ^ b, n3 = l0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+// [0,1) with 24 random bits, like torch's CPU/GPU uniform for fp32
+__host__ __device__ inline float u32_to_unit_float(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// [0,1) with 53 random bits, like numpy's random_sample
+__host__ __device__ inline double u64_to_unit_double(uint32_t hi, uint32_t lo) {
+    uint64_t a = hi >> 5, b = lo >> 6;  // 27 + 26 bits
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+// priority exponent with the same special cases torch.pow uses for scalar exponents
+// (0.5 -> sqrt, -0.5 -> 1/sqrt), so the default alpha = beta = 0.5 is correctly rounded on both
+// host and device.
+__host__ __device__ inline float pow_alpha(float x, float alpha) {
+    if (alpha == 0.5f) return sqrtf(x);
+    if (alpha == 1.0f) return x;
+    return powf(x, alpha);
+}
+__host__ __device__ inline float pow_neg_beta(float x, float beta) {
+    if (beta == 0.5f) return 1.0f / sqrtf(x);
+    if (beta == 1.0f) return 1.0f / x;
+    if (beta == 0.0f) return 1.0f;
+    return powf(x, -beta);
+}
+
+}  // namespace prism

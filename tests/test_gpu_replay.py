@@ -1,0 +1,247 @@
+"""GPU parity: HBM replay ring + PER trees (through the C ABI) vs the CPU oracle.
+Bit-exact bar: sampled indices, tree nodes, IS weights (alpha = beta = 0.5 uses correctly
+rounded sqrt/div on both sides), n-step returns, gathered rows."""
+import os
+import weakref
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return "cuda:0"
+
+
+def _mk_buffer(dev, capacity, B, O_shape=(10, 10, 4), **kw):
+    from prism_amd.experience import HipReplayBuffer
+    return HipReplayBuffer(capacity, B, device=dev, **kw)
+
+
+def _chain_timesteps():
+    """Rebuild linked Timestep objects from the golden chain, in insertion order."""
+    from prism_amd.experience import Timestep
+    g = np.load(os.path.join(H.GOLDEN, "nstep_chain.npz"))
+    N = int(g["N"])
+    ts = [Timestep(id=i) for i in range(N)]
+    keep = []
+    for i, t in enumerate(ts):
+        t.obs = torch.from_numpy(g["obs"][i])
+        t.reward, t.action = float(g["reward"][i]), int(g["action"][i])
+        t.done, t.truncated = bool(g["done"][i]), bool(g["truncated"][i])
+        if t.truncated:
+            t.next = Timestep(id=10_000 + i, obs=torch.from_numpy(g["succ_obs"][i]))
+        elif g["has_next"][i]:
+            if g["link"][i] >= 0:
+                t.next = weakref.ref(ts[int(g["link"][i])])
+            else:
+                node = Timestep(id=20_000 + i, obs=torch.from_numpy(g["succ_obs"][i]))
+                keep.append(node)
+                t.next = weakref.ref(node)
+    return g, ts, keep
+
+
+def test_extend_then_gather_matches_reference_chain(dev):
+    g, ts, keep = _chain_timesteps()
+    N = len(ts)
+    buf = _mk_buffer(dev, N + 9, N, n_step=int(g["n_step"]), gamma=float(g["gamma"]), use_per=True)
+    for t in ts:
+        buf.extend(t)
+    batch, info = buf.sample(return_info=True)       # flushes; sampled rows are random
+    # gather every slot in order through the C ABI
+    import ctypes
+    from prism_amd import _native as Nn
+    idx = torch.arange(N, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev):
+        Nn.check(Nn.lib().prism_replay_gather(ctypes.byref(buf._desc), Nn.ptr(idx), N, Nn.ptr(buf._obs),
+                                              Nn.ptr(buf._next_obs), Nn.ptr(buf._reward), Nn.ptr(buf._nonterminal),
+                                              Nn.ptr(buf._gamma), Nn.ptr(buf._action), Nn.current_stream_handle()),
+                 "gather")
+    torch.cuda.synchronize()
+    b = buf.get_static_batch()
+    np.testing.assert_array_equal(b["next"]["reward"].cpu().numpy(), g["exp_batch_reward"])
+    np.testing.assert_array_equal(b["gamma"].cpu().numpy(), g["exp_batch_gamma"])
+    np.testing.assert_array_equal(b["nonterminal"].cpu().numpy(), g["exp_batch_nonterminal"])
+    np.testing.assert_array_equal(b["action"].cpu().numpy(), g["exp_batch_action"])
+    np.testing.assert_array_equal(b["observation"].cpu().numpy(), g["exp_batch_obs"])
+    np.testing.assert_array_equal(b["next"]["observation"].cpu().numpy(), g["exp_batch_next_obs"])
+    # links built through the pending-successor map equal the reference's object graph
+    np.testing.assert_array_equal(buf.link[:N].cpu().numpy(), g["link"])
+    assert batch["observation"].shape == (N, 1, 10, 10, 4) and info["index"].dtype == torch.int64
+    assert int(info["index"].max()) < N and float(info["_weight"].max()) <= 1.0
+
+
+def _random_ring(rng, n, O=400):
+    obs = (rng.random((n, O)) < 0.1).astype(np.float32)
+    succ = (rng.random((n, O)) < 0.1).astype(np.float32)
+    reward = rng.standard_normal(n).astype(np.float32)
+    action = rng.integers(0, 6, n).astype(np.int32)
+    done = rng.random(n) < 0.05
+    trunc = (~done) & (rng.random(n) < 0.03)
+    has_next = ~done | trunc
+    link = np.where(~done & ~trunc & (rng.random(n) < 0.97), (np.arange(n) + 8) % n, -1).astype(np.int32)
+    link[-8:] = -1
+    flags = (done * 1 + trunc * 2 + has_next * 4).astype(np.uint8)
+    return obs, succ, reward, action, flags, link
+
+
+@pytest.mark.parametrize("capacity,n,B", [(1000, 700, 256), (1000, 1000, 512), (100_000, 100_000, 256)])
+def test_per_sample_update_bit_exact(dev, capacity, n, B):
+    from oracle import per_ref
+    rng = np.random.default_rng(capacity + n)
+    obs, succ, reward, action, flags, link = _random_ring(rng, n)
+    prio = (np.abs(rng.standard_normal(n)).astype(np.float32) + np.float32(1e-8)) ** np.float32(0.5)
+    # oracle
+    orc = per_ref.ReplayOracle(capacity, 400, 3, 0.99)
+    orc.obs[:n], orc.succ_obs[:n], orc.reward[:n], orc.action[:n] = obs, succ, reward, action
+    orc.flags[:n], orc.link[:n], orc.length = flags, link, n
+    orc.sampler.sum_tree.update(np.arange(n), prio)
+    orc.sampler.min_tree.update(np.arange(n), prio)
+    # device
+    buf = _mk_buffer(dev, capacity, B, n_step=3, gamma=0.99, use_per=True)
+    buf.load_arrays(torch.from_numpy(obs.reshape(n, 10, 10, 4)), torch.from_numpy(succ), torch.from_numpy(reward),
+                    torch.from_numpy(action), torch.from_numpy(flags), torch.from_numpy(link),
+                    torch.from_numpy(prio))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), orc.sampler.sum_tree.values())
+    np.testing.assert_array_equal(buf.min_tree.cpu().numpy()[1:], orc.sampler.min_tree.values()[1:])
+
+    import ctypes
+    from prism_amd import _native as Nn
+    for rnd in range(4):
+        mass = orc.sampler.draw_mass(n, B, np.random.RandomState(rnd))
+        if rnd == 3:
+            mass[:4] = [0.0, np.float32(orc.sampler.sum_tree.values()[1]), np.float32(3e38), mass[5]]
+        idx_o, w_o, psum_o, pmin_o = orc.sampler.sample(n, mass)
+        m_d = torch.from_numpy(mass).to(dev)
+        with torch.cuda.device(dev):
+            Nn.check(Nn.lib().prism_per_sample(ctypes.byref(buf._desc), n, B, Nn.ptr(m_d), 0, 0, 0.5,
+                                               Nn.ptr(buf._index), Nn.ptr(buf._weight),
+                                               Nn.current_stream_handle()), "sample")
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(buf._index.cpu().numpy(), idx_o)          # bit-exact indices
+        np.testing.assert_array_equal(buf._weight.cpu().numpy(), w_o)
+        ps = buf.per_state.cpu().numpy()
+        assert ps[1] == np.float32(psum_o) and ps[2] == np.float32(pmin_o)
+        # gather of the sampled rows
+        out = orc.gather(idx_o)
+        with torch.cuda.device(dev):
+            Nn.check(Nn.lib().prism_replay_gather(ctypes.byref(buf._desc), Nn.ptr(buf._index), B, Nn.ptr(buf._obs),
+                                                  Nn.ptr(buf._next_obs), Nn.ptr(buf._reward),
+                                                  Nn.ptr(buf._nonterminal), Nn.ptr(buf._gamma), Nn.ptr(buf._action),
+                                                  Nn.current_stream_handle()), "gather")
+        torch.cuda.synchronize()
+        b = buf.get_static_batch()
+        np.testing.assert_array_equal(b["next"]["reward"].cpu().numpy().ravel(), out["reward"])
+        np.testing.assert_array_equal(b["gamma"].cpu().numpy().ravel(), out["gamma"])
+        np.testing.assert_array_equal(b["nonterminal"].cpu().numpy().ravel(), out["nonterminal"].astype(bool))
+        np.testing.assert_array_equal(b["action"].cpu().numpy().ravel(), out["action"])
+        np.testing.assert_array_equal(b["observation"].cpu().numpy().reshape(B, -1), out["obs"])
+        np.testing.assert_array_equal(b["next"]["observation"].cpu().numpy().reshape(B, -1), out["next_obs"])
+        # priority writeback with duplicates (sampling is with replacement)
+        td = rng.standard_normal(B).astype(np.float32)
+        orc.sampler.update_priority(idx_o, np.abs(td))
+        buf.update_priority(buf._index, torch.from_numpy(td).to(dev), take_abs=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), orc.sampler.sum_tree.values())
+        np.testing.assert_array_equal(buf.min_tree.cpu().numpy()[1:], orc.sampler.min_tree.values()[1:])
+        assert buf.per_state.cpu().numpy()[0] == np.float32(orc.sampler.max_priority)
+
+
+def test_insert_default_priority_and_overwrite(dev):
+    """Round-robin overwrite past capacity; new rows get (max+eps)**alpha; trees stay consistent."""
+    from oracle import per_ref
+    from prism_amd.experience import Timestep
+    cap, B = 50, 16
+    buf = _mk_buffer(dev, cap, B, n_step=3, gamma=0.99, use_per=True)
+    orc = per_ref.ReplayOracle(cap, 400, 3, 0.99)
+    rng = np.random.default_rng(3)
+    cur = Timestep(id=0, obs=torch.from_numpy((rng.random((10, 10, 4)) < 0.1).astype(np.float32)))
+    prev_slot = -1
+    for i in range(130):
+        nxt = Timestep(id=i + 1, obs=torch.from_numpy((rng.random((10, 10, 4)) < 0.1).astype(np.float32)))
+        cur.reward, cur.action = float(np.float32(rng.standard_normal())), int(rng.integers(0, 6))
+        cur.done, cur.truncated = bool(i % 11 == 10), False
+        if not cur.done:
+            cur.next = weakref.ref(nxt)
+        s = buf.extend(cur)
+        so = orc.insert(cur.obs.numpy(), nxt.obs.numpy() if not cur.done else None, cur.reward, cur.action,
+                        cur.done, False, not cur.done, prev_slot)
+        assert s == so
+        prev_slot = -1 if cur.done else s
+        if i % 37 == 36:      # interleave a sample + writeback so max_priority moves
+            buf.flush()
+            idx = torch.from_numpy(rng.integers(0, len(buf), B)).to(dev)
+            td = torch.from_numpy((rng.random(B) * 3).astype(np.float32)).to(dev)
+            buf.update_priority(idx, td)
+            orc.sampler.update_priority(idx.cpu().numpy(), td.cpu().numpy())
+        cur = nxt
+    buf.flush()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), orc.sampler.sum_tree.values())
+    np.testing.assert_array_equal(buf.link.cpu().numpy(), orc.link)
+    np.testing.assert_array_equal(buf.flags.cpu().numpy(), orc.flags)
+    np.testing.assert_array_equal(buf.obs.cpu().numpy(), orc.obs)
+    np.testing.assert_array_equal(buf.succ_obs.cpu().numpy(), orc.succ_obs)
+    out = orc.gather(np.arange(cap))
+    import ctypes
+    from prism_amd import _native as Nn
+    idx = torch.arange(cap, device=dev)
+    buf._alloc_batch(cap)
+    with torch.cuda.device(dev):
+        Nn.check(Nn.lib().prism_replay_gather(ctypes.byref(buf._desc), Nn.ptr(idx), cap, Nn.ptr(buf._obs),
+                                              Nn.ptr(buf._next_obs), Nn.ptr(buf._reward), Nn.ptr(buf._nonterminal),
+                                              Nn.ptr(buf._gamma), Nn.ptr(buf._action), Nn.current_stream_handle()),
+                 "gather")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(buf._reward.cpu().numpy().ravel(), out["reward"])
+    np.testing.assert_array_equal(buf._gamma.cpu().numpy().ravel(), out["gamma"])
+    np.testing.assert_array_equal(buf._next_obs.cpu().numpy().reshape(cap, -1), out["next_obs"])
+
+
+def test_philox_sampling_follows_priorities(dev):
+    n, B = 4096, 4096
+    buf = _mk_buffer(dev, n, B, use_per=True)
+    rng = np.random.default_rng(0)
+    obs, succ, reward, action, flags, link = _random_ring(rng, n)
+    prio = np.ones(n, np.float32)
+    prio[:n // 2] = 3.0
+    buf.load_arrays(torch.from_numpy(obs.reshape(n, 10, 10, 4)), torch.from_numpy(succ), torch.from_numpy(reward),
+                    torch.from_numpy(action), torch.from_numpy(flags), torch.from_numpy(link), torch.from_numpy(prio))
+    counts = 0
+    for _ in range(8):
+        _, info = buf.sample(return_info=True)
+        idx = info["index"].cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < n
+        counts += (idx < n // 2).sum()
+    frac = counts / (8 * B)
+    assert abs(frac - 0.75) < 0.02
+    w = info["_weight"].cpu().numpy()
+    assert set(np.unique(w)).issubset({np.float32(1.0), np.float32(1.0) / np.sqrt(np.float32(3.0))})
+    buf.check_status()
+
+
+def test_uniform_replay_and_empty_errors(dev):
+    buf = _mk_buffer(dev, 100, 8, use_per=False)
+    with pytest.raises(RuntimeError):
+        buf.sample()
+    rng = np.random.default_rng(0)
+    obs, succ, reward, action, flags, link = _random_ring(rng, 60)
+    buf.load_arrays(torch.from_numpy(obs.reshape(60, 10, 10, 4)), torch.from_numpy(succ), torch.from_numpy(reward),
+                    torch.from_numpy(action), torch.from_numpy(flags), torch.from_numpy(link))
+    b, info = buf.sample(return_info=True)
+    assert "_weight" not in info and int(info["index"].max()) < 60
+    # all-zero priorities: torchrl raises at sample time; here the sticky status word does
+    pbuf = _mk_buffer(dev, 100, 8, use_per=True, strict=True)
+    pbuf.load_arrays(torch.from_numpy(obs.reshape(60, 10, 10, 4)), torch.from_numpy(succ), torch.from_numpy(reward),
+                     torch.from_numpy(action), torch.from_numpy(flags), torch.from_numpy(link),
+                     torch.zeros(60))
+    with pytest.raises(RuntimeError):
+        pbuf.sample()
