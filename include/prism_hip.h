@@ -173,7 +173,7 @@ typedef struct prism_param_offsets {
 } prism_param_offsets;
 
 typedef struct prism_adam_hyper {
-    float lr, beta1, beta2, eps;
+    double lr, beta1, beta2, eps; /* doubles: torch evaluates the bias corrections in Python floats */
     float max_grad_norm;
     float grad_scale;      /* multiplied into the gradient before the norm (1/world_size)    */
 } prism_adam_hyper;

@@ -49,7 +49,8 @@ class ParamOffsets(ctypes.Structure):
 
 
 class AdamHyper(ctypes.Structure):
-    _fields_ = [(n, c_f32) for n in ("lr", "beta1", "beta2", "eps", "max_grad_norm", "grad_scale")]
+    _fields_ = [(n, ctypes.c_double) for n in ("lr", "beta1", "beta2", "eps")] + \
+               [(n, c_f32) for n in ("max_grad_norm", "grad_scale")]
 
 
 class LearnerDesc(ctypes.Structure):

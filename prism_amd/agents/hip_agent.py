@@ -1,0 +1,370 @@
+"""``HipAgent`` — duck-types the reference ``Agent`` (``/root/reference/prism/agents/agent.py``)
+with the TD update running in the hand-written gfx950 kernels behind ``prism_learner_fwd_bwd`` /
+``prism_learner_clip_adam``.
+
+Memory model: ONE flat fp32 parameter buffer per network in ``model.parameters()`` order
+(SURVEY.md Appendix B); every ``nn.Parameter`` of the container modules is a view into it, so
+``state_dict()`` / checkpoints interchange with the reference while the kernels and the RCCL
+all-reduce see a single contiguous buffer.  Adam moments and the gradient are flat buffers too.
+
+Data-parallel: ``torch.distributed`` all-reduce (RCCL over xGMI) of the flat gradient sits
+between the two native calls; clip + Adam then run redundantly on every rank so replicas stay
+bit-identical.
+"""
+import ctypes
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from prism_amd import _native as N
+
+
+class HipAdam:
+    """Flat Adam state with a ``torch.optim.Adam``-compatible ``state_dict`` (the update itself is
+    the fused kernel).  Mirrors the options of agent_factory.py:44-47."""
+
+    def __init__(self, named_params, flat_params, lr, betas, eps):
+        self.names = [n for n, _ in named_params]
+        self.shapes = [tuple(p.shape) for _, p in named_params]
+        self.numels = [p.numel() for _, p in named_params]
+        self.flat_params = flat_params
+        dev = flat_params.device
+        self.exp_avg = torch.zeros_like(flat_params)
+        self.exp_avg_sq = torch.zeros_like(flat_params)
+        self.step_t = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False,
+                                  fused=None, params=list(range(len(self.names))))]
+
+    def zero_grad(self, set_to_none=True):
+        pass
+
+    def state_dict(self):
+        state, off = {}, 0
+        step = float(self.step_t.item())
+        for i, (n, shp) in enumerate(zip(self.numels, self.shapes)):
+            if step > 0:
+                state[i] = {"step": torch.tensor(step), "exp_avg": self.exp_avg[off:off + n].view(shp).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(shp).clone()}
+            off += n
+        return {"state": state, "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        off, step = 0, 0
+        for i, (n, shp) in enumerate(zip(self.numels, self.shapes)):
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(float(st["step"]))
+            off += n
+        self.step_t.fill_(step)
+        if sd.get("param_groups"):
+            g = sd["param_groups"][0]
+            for k in ("lr", "betas", "eps"):
+                if k in g:
+                    self.param_groups[0][k] = g[k]
+
+
+def _flatten_into(model, device):
+    """Move every parameter into one contiguous fp32 buffer (parameters() order) and re-point the
+    parameters at views of it."""
+    params = list(model.parameters())
+    flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        flat[off:off + n].copy_(p.data.reshape(-1))
+        p.data = flat[off:off + n].view(p.shape)
+        off += n
+    return flat
+
+
+def _offsets(model):
+    """state_dict key -> flat offset, mapped onto the C ABI's prism_param_offsets."""
+    off, table = 0, {}
+    for name, p in model.named_parameters():
+        table[name] = off
+        off += p.numel()
+    o = N.ParamOffsets()
+    for f, _ in N.ParamOffsets._fields_:
+        setattr(o, f, -1)
+    o.n_params = off
+    g = table.get
+    o.conv_w, o.conv_b = g("embedding_model.model.0.weight", -1), g("embedding_model.model.0.bias", -1)
+    d = "distribution_model."
+    o.phi_w, o.phi_b = g(d + "phi.0.weight", -1), g(d + "phi.0.bias", -1)
+    o.iqn_ln1_g, o.iqn_ln1_b = g(d + "model.model.0.weight", -1), g(d + "model.model.0.bias", -1)
+    o.iqn_w1, o.iqn_b1 = g(d + "model.model.1.weight", -1), g(d + "model.model.1.bias", -1)
+    o.iqn_ln2_g = g(d + "embedding_to_quantile_layer.0.weight", -1)
+    o.iqn_ln2_b = g(d + "embedding_to_quantile_layer.0.bias", -1)
+    o.iqn_w2 = g(d + "embedding_to_quantile_layer.1.weight", -1)
+    o.iqn_b2 = g(d + "embedding_to_quantile_layer.1.bias", -1)
+    heads = sorted({int(k.split(".")[2]) for k in table if k.startswith("q_function_model.q_heads.")})
+    if heads:
+        pre = "q_function_model.q_heads.0."
+        names = [k[len(pre):] for k in table if k.startswith(pre)]
+        o.head_base = min(table[pre + n] for n in names)
+        if len(heads) > 1:
+            o.head_stride = table["q_function_model.q_heads.1." + names[0]] - table[pre + names[0]]
+        else:
+            o.head_stride = 0
+        rel = {n: table[pre + n] - o.head_base for n in names}
+        # FFNN-style head: model.{0:LN,1:Linear,3:LN,4:Linear} | model.{0:Linear} | model.{0:LN,1:Linear}
+        order = sorted(rel, key=lambda n: rel[n])
+        lin = [n[:-len(".weight")] for n in order if n.endswith(".weight") and (n[:-len(".weight")] + ".bias") in rel
+               and len(dict(model.named_parameters())[pre + n].shape) == 2]
+        lns = [n[:-len(".weight")] for n in order if n.endswith(".weight") and n[:-len(".weight")] not in lin]
+        if len(lin) >= 1:
+            o.h_w1, o.h_b1 = rel[lin[0] + ".weight"], rel[lin[0] + ".bias"]
+        if len(lin) >= 2:
+            o.h_w2, o.h_b2 = rel[lin[1] + ".weight"], rel[lin[1] + ".bias"]
+        if len(lns) >= 1:
+            o.h_ln1_g, o.h_ln1_b = rel[lns[0] + ".weight"], rel[lns[0] + ".bias"]
+        if len(lns) >= 2:
+            o.h_ln2_g, o.h_ln2_b = rel[lns[1] + ".weight"], rel[lns[1] + ".bias"]
+    return o
+
+
+def model_dims(config, in_channels, n_actions):
+    d = N.ModelDims()
+    d.in_channels, d.n_actions, d.embed_dim = int(in_channels), int(n_actions), 1024
+    d.use_iqn = int(bool(config.use_iqn))
+    d.n_basis, d.iqn_layers = config.iqn_n_basis_elements, config.iqn_quantile_model_layers
+    d.iqn_width = config.iqn_quantile_model_feature_dim
+    d.n_tau, d.n_tau_next = config.iqn_n_current_state_quantile_samples, config.iqn_n_next_state_quantile_samples
+    d.use_layer_norm = int(bool(config.use_layer_norm))
+    if config.use_ids:
+        d.n_heads, d.head_layers, d.head_width = (config.ids_n_q_heads, config.ids_n_q_head_model_layers,
+                                                  config.ids_q_head_feature_dim)
+        d.theil_coef = config.ids_ensemble_variation_coef
+    elif config.use_dqn:
+        d.n_heads, d.head_layers, d.head_width = 1, config.dqn_n_model_layers, config.dqn_n_model_feature_dim
+        d.theil_coef = 0.0
+    d.has_target = int(bool(config.use_target_network))
+    d.double_q = int(bool(config.use_double_q_learning))
+    d.propagate_grad = int((config.ids_allow_distributional_gradients and config.use_ids) or not config.use_ids)
+    d.huber_k, d.dist_loss_weight = config.iqn_huber_loss_kappa, config.distributional_loss_weight
+    d.q_loss_weight = config.q_loss_weight
+    return d
+
+
+class HipAgent:
+    def __init__(self, model, action_selector, eval_action_selector, target_model, config, in_channels,
+                 n_actions, process_group=None):
+        if not str(config.device).startswith("cuda"):
+            raise N.NativeLibraryError("HipAgent needs a GPU device; prism_amd has no CPU fallback")
+        N.lib()
+        self.device = torch.device(config.device)
+        self.config = config
+        self.model, self.target_model = model, target_model
+        self.action_selector, self.eval_action_selector = action_selector, eval_action_selector
+        self.max_grad_norm = config.max_grad_norm
+        self.use_cuda_graph = False
+        self.n_updates = 0
+        self._is_eval = False
+        self._static_batch = None
+        self._static_distribution_loss = None
+        self._static_q_loss = None
+        self._static_total_loss = None
+
+        self.flat = _flatten_into(model, self.device)
+        self.flat_target = _flatten_into(target_model, self.device) if target_model is not None else None
+        self.grads = torch.zeros_like(self.flat)
+        self.optimizer = HipAdam(list(model.named_parameters()), self.flat, config.learning_rate,
+                                 (config.adam_beta1, config.adam_beta2), config.adam_epsilon)
+        self.dims = model_dims(config, in_channels, n_actions)
+        self.off = _offsets(model)
+        self.tau_rng = getattr(config, "tau_rng", "philox")
+        self.seed = int(config.seed)
+        self._draw_offset = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                         and getattr(config, "data_parallel", False)):
+            self.world = torch.distributed.get_world_size(process_group)
+        self._B = None
+        self.model.train()
+
+    # ------------------------------------------------------------------ descriptor
+    def _prepare(self, B):
+        L = N.lib()
+        rc = L.prism_learner_supported(ctypes.byref(self.dims), B)
+        if rc != N.PRISM_OK:
+            from prism_amd.factory.model_factory import UnsupportedConfig
+            raise UnsupportedConfig(
+                f"prism_amd HIP learner does not cover this configuration at batch {B} "
+                f"(use_iqn={self.dims.use_iqn}, n_heads={self.dims.n_heads}, layer_norm={self.dims.use_layer_norm}, "
+                f"T={self.dims.n_tau}); there is no eager fallback")
+        dev = self.device
+        ws_bytes = L.prism_learner_workspace_bytes(ctypes.byref(self.dims), B)
+        self.workspace = torch.zeros((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        self.out_dl = torch.zeros(B, device=dev)
+        self.out_ql = torch.zeros(B, device=dev)
+        self.out_td = torch.zeros(B, device=dev)
+        self.scalars = torch.zeros(8, device=dev)
+        maxT = max(self.dims.n_tau, self.dims.n_tau_next)
+        self.tau_out = torch.zeros(3, maxT * B, device=dev)
+        self.ones_w = None
+        d = N.LearnerDesc()
+        d.dims, d.off, d.batch = self.dims, self.off, B
+        d.params, d.grads = self.flat.data_ptr(), self.grads.data_ptr()
+        d.target_params = self.flat_target.data_ptr() if self.flat_target is not None else None
+        d.adam_m, d.adam_v = self.optimizer.exp_avg.data_ptr(), self.optimizer.exp_avg_sq.data_ptr()
+        d.adam_step = self.optimizer.step_t.data_ptr()
+        d.tau_out = self.tau_out.data_ptr()
+        d.out_dist_loss, d.out_q_loss = self.out_dl.data_ptr(), self.out_ql.data_ptr()
+        d.out_td, d.out_scalars = self.out_td.data_ptr(), self.scalars.data_ptr()
+        d.workspace, d.workspace_bytes = self.workspace.data_ptr(), ws_bytes
+        d.seed = self.seed
+        self._desc, self._B = d, B
+
+    def _set_hyper(self):
+        g, h = self.optimizer.param_groups[0], self._desc.hyper
+        h.lr, h.beta1, h.beta2, h.eps = g["lr"], g["betas"][0], g["betas"][1], g["eps"]
+        h.max_grad_norm, h.grad_scale = self.max_grad_norm, 1.0 / self.world
+
+    # ------------------------------------------------------------------ reference API
+    def update(self, batch, per_weights=1, taus=None):
+        """One TD update (agent.py:43-79).  ``taus``: optional explicit quantile samples in the
+        reference's draw order (parity tests); otherwise drawn in-kernel (Philox) or with
+        ``torch.rand`` when ``config.tau_rng == 'torch'``."""
+        self.train()
+        obs = batch["observation"]
+        B = int(obs.shape[0])
+        if self._B != B:
+            self._prepare(B)
+        d = self._desc
+        nobs, rew = batch["next"]["observation"], batch["next"]["reward"]
+        act = batch["action"]
+        if act.dim() == 2 and act.shape[-1] != 1:
+            act = act.argmax(dim=-1)
+        keep = [obs.float().contiguous(), nobs.float().contiguous(), rew.float().contiguous(),
+                batch["nonterminal"].contiguous(), batch["gamma"].float().contiguous(),
+                act.long().contiguous()]
+        d.obs, d.next_obs, d.reward, d.nonterminal, d.gamma, d.action = [t.data_ptr() for t in keep]
+        if torch.is_tensor(per_weights):
+            w = per_weights.to(self.device, torch.float32).contiguous()
+            keep.append(w)
+            d.per_weights = w.data_ptr()
+        else:
+            if float(per_weights) != 1.0:
+                w = torch.full((B,), float(per_weights), device=self.device)
+                keep.append(w)
+                d.per_weights = w.data_ptr()
+            else:
+                d.per_weights = None
+        if taus is None and self.tau_rng == "torch" and self.dims.use_iqn:
+            T, Tn = self.dims.n_tau, self.dims.n_tau_next
+            taus = [torch.rand([T * B, 1], device=self.device)]
+            if not self.dims.has_target or self.dims.double_q:
+                taus.append(torch.rand([Tn * B, 1], device=self.device))
+            if self.dims.has_target:
+                taus.append(torch.rand([Tn * B, 1], device=self.device))
+        d.tau_cur = d.tau_next_online = d.tau_next_target = None
+        if taus is not None:
+            ts = [t.to(self.device, torch.float32).reshape(-1).contiguous() for t in taus]
+            keep.extend(ts)
+            it = iter(ts)
+            d.tau_cur = next(it).data_ptr()
+            if not self.dims.has_target or self.dims.double_q:
+                d.tau_next_online = next(it).data_ptr()
+            if self.dims.has_target:
+                d.tau_next_target = next(it).data_ptr()
+        d.offset = self._draw_offset
+        self._draw_offset += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * B
+        self._set_hyper()
+        L = N.lib()
+        with torch.cuda.device(self.device):
+            N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), N.current_stream_handle()), "prism_learner_fwd_bwd")
+            if self.world > 1:
+                torch.distributed.all_reduce(self.grads, group=self.pg)
+            N.check(L.prism_learner_clip_adam(ctypes.byref(d), N.current_stream_handle()), "prism_learner_clip_adam")
+        self._keep = keep
+        self._static_total_loss = self.scalars[0]
+        self._static_distribution_loss = self.out_dl if self.dims.use_iqn else None
+        self._static_q_loss = self.out_ql if self.dims.n_heads > 0 else None
+        self.n_updates += 1
+        return self.out_td
+
+    @torch.no_grad()
+    def forward(self, obs):
+        q, dist = self.model(obs, for_action=True)
+        sel = self.eval_action_selector if self._is_eval else self.action_selector
+        return sel.select_action(sel.generate_action_probs(dist, q))
+
+    @torch.no_grad()
+    def sync_target_model(self):
+        with torch.cuda.device(self.device):
+            N.check(N.lib().prism_sync_target(N.ptr(self.flat_target), N.ptr(self.flat), self.flat.numel(),
+                                              N.current_stream_handle()), "prism_sync_target")
+
+    def set_static_batch(self, batch):
+        self._static_batch = batch
+
+    def get_static_batch(self):
+        return self._static_batch
+
+    def eval(self):
+        self.model.eval()
+        self._is_eval = True
+
+    def train(self):
+        self.model.train()
+        self._is_eval = False
+
+    def serialize_model(self):
+        return self.flat.tolist() if not list(self.model.buffers()) else \
+            [x for v in self.model.state_dict().values() for x in v.flatten().tolist()]
+
+    def deserialize_model(self, values):
+        self.flat.copy_(torch.as_tensor(values, dtype=torch.float32))
+
+    def save(self, directory):
+        """File layout of agent.py:179-203 (reference checkpoints interchange)."""
+        path = os.path.join(directory, "agent")
+        os.makedirs(path, exist_ok=True)
+        torch.save(self.model.state_dict(), os.path.join(path, "model.pt"))
+        torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pt"))
+        if self.target_model is not None:
+            torch.save(self.target_model.state_dict(), os.path.join(path, "target_model.pt"))
+        state = {"action_selector": self.action_selector, "n_updates": self.n_updates,
+                 "eval_action_selector": self.eval_action_selector, "max_grad_norm": self.max_grad_norm,
+                 "use_cuda_graph": self.use_cuda_graph}
+        with open(os.path.join(path, "state.pkl"), "wb") as f:
+            pickle.dump(state, f)
+
+    def load(self, directory):
+        path = os.path.join(directory, "agent")
+        # load_state_dict copies INTO the existing parameters, i.e. into the flat buffer views
+        self.model.load_state_dict(torch.load(os.path.join(path, "model.pt"), map_location=self.device))
+        self.optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.pt"), map_location=self.device))
+        if self.target_model is not None:
+            self.target_model.load_state_dict(torch.load(os.path.join(path, "target_model.pt"),
+                                                         map_location=self.device))
+        with open(os.path.join(path, "state.pkl"), "rb") as f:
+            state = pickle.load(f)
+        self.action_selector = state["action_selector"]
+        self.eval_action_selector = state["eval_action_selector"]
+        self.max_grad_norm = state["max_grad_norm"]
+        self.n_updates = state["n_updates"]
+        self.train()
+
+    @torch.no_grad()
+    def log(self, logger):
+        logger.log_data(data=float(self._static_total_loss), group_name="Report/Losses", var_name="Total Loss")
+        if self._static_distribution_loss is not None:
+            logger.log_data(data=float(self._static_distribution_loss.mean()), group_name="Report/Losses",
+                            var_name="Distribution Loss")
+        if self._static_q_loss is not None:
+            logger.log_data(data=float(self._static_q_loss.mean()), group_name="Report/Losses", var_name="Q Loss")
+        if getattr(logger, "holdout_data", None) is not None:
+            idx = np.random.randint(0, logger.holdout_data["observation"].shape[0])
+            obs = logger.holdout_data["observation"][idx]
+            if obs.shape[0] != 1:
+                obs = obs.unsqueeze(0)
+            q, dist = self.model(obs)
+            self.action_selector.log(logger, dist, q)
+        self.model.log(logger)

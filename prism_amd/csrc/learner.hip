@@ -1,12 +1,329 @@
-// placeholder entry points; replaced by the fused kernels
-#include "common.h"
-extern "C" size_t prism_learner_workspace_bytes(const prism_model_dims *, int32_t) { return 0; }
-extern "C" int prism_learner_supported(const prism_model_dims *, int32_t) { return PRISM_ERR_UNSUPPORTED; }
-extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *, prism_stream_t) {
-    prism::set_error("not built yet");
-    return PRISM_ERR_UNSUPPORTED;
+// TD update entry points: get_losses + backward (prism_learner_fwd_bwd) and
+// clip_grad_norm_ + Adam (prism_learner_clip_adam).  Reference:
+//   /root/reference/prism/agents/models/composite_model.py:94-144, prism/agents/agent.py:53-79.
+#include <math.h>
+#include <string.h>
+
+#include "iqn_kernels.h"
+
+namespace prism {
+
+// ---- global-norm clip + Adam over the flat buffers ---------------------------------------------
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+    int64_t *step;
+    const float *normpart;
+    int n_front, use_tail;
+    double lr, b1, b2, eps;
+    float max_norm, grad_scale;
+    float *out_scalars;
+    unsigned int *ticket;
+};
+
+// sum of squares of the (scaled) gradient, one partial per block — data-parallel path, where the
+// partials written by the backward kernels predate the all-reduce
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict__ g, int64_t n, float scale,
+                                                        float *__restrict__ normpart) {
+    __shared__ float s_red[256];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = g[i] * scale;
+        s += x * x;
+    }
+    s_red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) normpart[blockIdx.x] = s_red[0];
 }
-extern "C" int prism_learner_clip_adam(const prism_learner_desc *, prism_stream_t) {
-    prism::set_error("not built yet");
-    return PRISM_ERR_UNSUPPORTED;
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) {
+    __shared__ float s_red[256];
+    __shared__ float s_coef;
+    const int tid = threadIdx.x;
+    // every block folds the same partials in the same order -> identical norm everywhere
+    float s = 0.f;
+    for (int i = tid; i < a.n_front; i += 256) s += a.normpart[i];
+    if (tid == 0 && a.use_tail) s += a.normpart[NORM_SLOTS - 1];
+    s_red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float total = sqrtf(s_red[0]);
+        float coef = a.max_norm / (total + 1e-6f);   // torch.nn.utils.clip_grad_norm_
+        coef = fminf(coef, 1.0f);
+        s_coef = coef;
+        if (blockIdx.x == 0) {
+            a.out_scalars[3] = total;
+            a.out_scalars[5] = coef;
+        }
+    }
+    __syncthreads();
+    const float coef = s_coef;
+    // torch.optim.Adam (_single_tensor_adam): bias corrections in float64 from the step count
+    const double t = (double)(a.step[0] + 1);
+    const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
+    const float neg_step = (float)(-(a.lr / bc1));
+    const float bc2s = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - a.b1), b2f = (float)a.b2, w2 = (float)(1.0 - a.b2), epsf = (float)a.eps;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.n; i += (int64_t)gridDim.x * 256) {
+        const float g = (a.g[i] * a.grad_scale) * coef;
+        float m = a.m[i], v = a.v[i];
+        m = fmaf(w1, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * b2f + (w2 * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+        const float denom = sqrtf(v) / bc2s + epsf;
+        a.p[i] = a.p[i] + (neg_step * m) / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
+        a.m[i] = m;
+        a.v[i] = v;
+    }
+    // the block that finishes last advances the step counter (all blocks have read it by then)
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned int done = atomicAdd(a.ticket, 1u);
+        if (done == gridDim.x - 1) {
+            a.step[0] = a.step[0] + 1;
+            *a.ticket = 0u;
+        }
+    }
+}
+
+// ---- workspace carving -----------------------------------------------------------------------
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *b) : base((char *)b), off(0) {}
+    float *f(size_t n) {
+        float *p = base ? (float *)(base + off) : nullptr;
+        off += ((n + 3) / 4) * 16;   // n floats rounded up to 16 bytes
+        return p;
+    }
+};
+
+static int iqn_supported(const prism_model_dims *d, int32_t B) {
+    auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
+    if (!d->use_iqn || d->n_heads != 0) return PRISM_ERR_UNSUPPORTED;
+    if (d->embed_dim != E_DIM || d->n_basis != K_BASIS || d->iqn_layers != 1 || d->iqn_width != H_DIM ||
+        !d->use_layer_norm)
+        return PRISM_ERR_UNSUPPORTED;
+    if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
+    if (B < 1 || (B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
+    if (d->n_actions < 1 || d->n_actions > 16 || d->in_channels < 1 || d->in_channels > 10) return PRISM_ERR_UNSUPPORTED;
+    return PRISM_OK;
+}
+
+static constexpr int N_CHUNKS = 4;
+
+static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws, float **tau_buf, float **dl_buf) {
+    Carver c(base);
+    const size_t R = (size_t)B * d->n_tau, Rn = (size_t)B * d->n_tau_next, A = d->n_actions;
+    const size_t maxT = d->n_tau > d->n_tau_next ? d->n_tau : d->n_tau_next;
+    IqnWs w;
+    w.e_cur = c.f((size_t)B * E_DIM);
+    w.e_next = c.f((size_t)B * E_DIM);
+    w.uv = c.f(2 * H_DIM);
+    w.cosb = c.f(R * K_BASIS);
+    w.mu1 = c.f(R);
+    w.rstd1 = c.f(R);
+    w.pre1 = c.f(R * H_DIM);
+    w.xhat2 = c.f(R * H_DIM);
+    w.rstd2 = c.f(R);
+    w.zcur = c.f(R * A);
+    w.zon = c.f(Rn * A);
+    w.ztg = c.f(Rn * A);
+    w.dq = c.f(R);
+    w.c1 = c.f(R);
+    w.c2 = c.f(R);
+    w.dpre1 = c.f(R * H_DIM);
+    w.Sb = c.f((size_t)B * H_DIM);
+    w.Pb = c.f((size_t)B * H_DIM);
+    w.Db = c.f(B);
+    w.lossw = c.f(B);
+    w.de_iqn = c.f((size_t)B * E_DIM);
+    w.slabs = c.f((size_t)N_CHUNKS * SLAB);
+    w.convpart = c.f((size_t)16 * CONV_CHUNKS * 96);
+    w.normpart = c.f(NORM_SLOTS);
+    w.ticket = (unsigned int *)c.f(4);
+    float *tb = c.f(3 * maxT * B);
+    float *db = c.f(B);
+    if (ws) *ws = w;
+    if (tau_buf) *tau_buf = tb;
+    if (dl_buf) *dl_buf = db;
+    return c.off;
+}
+
+}  // namespace prism
+
+using namespace prism;
+
+extern "C" int prism_learner_supported(const prism_model_dims *dims, int32_t batch) {
+    if (!dims) return PRISM_ERR_INVALID;
+    return iqn_supported(dims, batch);
+}
+
+extern "C" size_t prism_learner_workspace_bytes(const prism_model_dims *dims, int32_t batch) {
+    if (!dims || iqn_supported(dims, batch) != PRISM_OK) return 0;
+    return carve_iqn(dims, batch, nullptr, nullptr, nullptr, nullptr);
+}
+
+static int check_learner(const prism_learner_desc *ld) {
+    PRISM_CHECK_ARG(ld != nullptr, "null descriptor");
+    if (iqn_supported(&ld->dims, ld->batch) != PRISM_OK) {
+        set_error("prism_learner: model dims / batch not covered by the HIP kernels "
+                  "(need use_iqn, LN on, E=1024, K=64, H=128, T in {4,8,16,32,64}, B*T %% 16 == 0, no Q heads yet)");
+        return PRISM_ERR_UNSUPPORTED;
+    }
+    PRISM_CHECK_ARG(ld->params && ld->grads && ld->adam_m && ld->adam_v && ld->adam_step, "null parameter buffers");
+    PRISM_CHECK_ARG(!ld->dims.has_target || ld->target_params, "has_target without target_params");
+    PRISM_CHECK_ARG(ld->workspace && ld->workspace_bytes >= prism_learner_workspace_bytes(&ld->dims, ld->batch),
+                    "workspace too small");
+    PRISM_CHECK_ARG(((uintptr_t)ld->workspace & 15) == 0, "workspace must be 16-byte aligned");
+    PRISM_CHECK_ARG(ld->off.n_params > 0, "n_params");
+    return PRISM_OK;
+}
+
+extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
+                    "null batch arrays");
+    PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
+    hipStream_t stream = (hipStream_t)stream_;
+    const prism_model_dims &d = ld->dims;
+    const int B = ld->batch;
+
+    IqnArgs a;
+    memset(&a, 0, sizeof(a));
+    float *tau_buf = nullptr, *dl_buf = nullptr;
+    carve_iqn(&d, B, ld->workspace, &a.ws, &tau_buf, &dl_buf);
+    a.B = B;
+    a.A = d.n_actions;
+    a.C = d.in_channels;
+    a.T = d.n_tau;
+    a.Tn = d.n_tau_next;
+    a.n_chunks = N_CHUNKS;
+    a.has_target = d.has_target;
+    a.double_q = d.double_q;
+    a.propagate_grad = d.propagate_grad;
+    a.huber_k = d.huber_k;
+    a.dist_w = d.dist_loss_weight;
+    a.off = ld->off;
+    a.params = ld->params;
+    a.target_params = ld->target_params;
+    a.obs = ld->obs;
+    a.next_obs = ld->next_obs;
+    a.reward = ld->reward;
+    a.gamma = ld->gamma;
+    a.per_weights = ld->per_weights;
+    a.nonterminal = ld->nonterminal;
+    a.action = ld->action;
+    a.seed = ld->seed;
+    a.offset = ld->offset;
+    a.tau_out = ld->tau_out ? ld->tau_out : tau_buf;
+    a.maxT = d.n_tau > d.n_tau_next ? d.n_tau : d.n_tau_next;
+    a.out_dl = ld->out_dist_loss ? ld->out_dist_loss : dl_buf;
+    a.out_td = ld->out_td;
+    a.out_scalars = ld->out_scalars;
+    a.grads = ld->grads;
+
+    // passes, in the reference's tau draw order (iqn_model.py:104,112-126)
+    int np = 0;
+    a.pass[np++] = IqnPass{ld->params, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau, B * d.n_tau / 16, 1, 0};
+    if (!d.has_target || d.double_q) {
+        a.pass[np++] = IqnPass{ld->params, a.ws.e_next, ld->tau_next_online, a.ws.zon, d.n_tau_next,
+                               B * d.n_tau_next / 16, 0, 1};
+    }
+    if (d.has_target) {
+        a.pass[np++] = IqnPass{ld->target_params, a.ws.e_next, ld->tau_next_target, a.ws.ztg, d.n_tau_next,
+                               B * d.n_tau_next / 16, 0, 2};
+    }
+    a.n_pass = np;
+    if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
+    else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
+    int total_tiles = 0;
+    for (int i = 0; i < np; ++i) total_tiles += a.pass[i].n_tiles;
+
+    static bool attr_set = false;
+    const size_t fwd_lds = TILE_FWD_LDS_FLOATS * sizeof(float);
+    const size_t bwd_lds = (size_t)(4 * BWD_ACC * 64 > 4 * BWD_WAVE_LDS ? 4 * BWD_ACC * 64 : 4 * BWD_WAVE_LDS) *
+                           sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)iqn_tile_fwd_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(tile_fwd, %zu): %s", fwd_lds, hipGetErrorString(e));
+            return PRISM_ERR_HIP;
+        }
+        attr_set = true;
+    }
+
+    hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4), dim3(256), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
+    PRISM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+    PRISM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iqn_small_kernel, dim3(16 * CONV_CHUNKS + 1), dim3(1024), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(iqn_reduce_kernel, dim3(REDUCE_BLOCKS), dim3(256), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    if (ld->dbg_z) {
+        const size_t R = (size_t)B * d.n_tau, Rn = (size_t)B * d.n_tau_next, A = d.n_actions;
+        hipMemcpyAsync(ld->dbg_z, a.ws.zcur, R * A * 4, hipMemcpyDeviceToDevice, stream);
+        hipMemcpyAsync(ld->dbg_z + R * A, a.ws.ztg, Rn * A * 4, hipMemcpyDeviceToDevice, stream);
+    }
+    return PRISM_OK;
+}
+
+extern "C" int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    PRISM_CHECK_ARG(ld->out_scalars, "null out_scalars");
+    hipStream_t stream = (hipStream_t)stream_;
+    IqnWs ws;
+    carve_iqn(&ld->dims, ld->batch, ld->workspace, &ws, nullptr, nullptr);
+    AdamArgs a;
+    a.p = ld->params;
+    a.g = ld->grads;
+    a.m = ld->adam_m;
+    a.v = ld->adam_v;
+    a.n = ld->off.n_params;
+    a.step = ld->adam_step;
+    a.normpart = ws.normpart;
+    a.lr = ld->hyper.lr;
+    a.b1 = ld->hyper.beta1;
+    a.b2 = ld->hyper.beta2;
+    a.eps = ld->hyper.eps;
+    a.max_norm = ld->hyper.max_grad_norm;
+    a.grad_scale = ld->hyper.grad_scale;
+    a.out_scalars = ld->out_scalars;
+    a.ticket = ws.ticket;
+    if (ld->hyper.grad_scale == 1.0f) {
+        // single replica: reuse the sum-of-squares partials the backward kernels left behind
+        a.n_front = REDUCE_BLOCKS;
+        a.use_tail = 1;
+    } else {
+        // data parallel: the gradient was all-reduced after the backward; recompute the partials
+        const int nb = 256;
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nb), dim3(256), 0, stream, ld->grads, a.n, a.grad_scale,
+                           ws.normpart);
+        PRISM_CHECK_LAUNCH();
+        a.n_front = nb;
+        a.use_tail = 0;
+    }
+    int blocks = (int)((a.n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    return PRISM_OK;
 }
