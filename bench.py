@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Learner grad-steps/sec on the replay-sample -> TD-update -> priority-writeback hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W            # BASELINE.json metric config (c3)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = Learner.step(): PER sample + n-step gather + IQN TD update (fwd, loss, bwd, clip, Adam)
++ priority writeback, on synthetic MinAtar/Breakout-shaped transitions already resident in HBM.
+N > 1: one process per GPU, replay sharded by capacity (each rank samples its own shard), one RCCL
+all-reduce of the flat gradient per step (weak scaling: per-GPU batch fixed).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
+HIP-event timed on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle
+port timed on this box's host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0             # HBM3E spec
+
+
+def algorithmic_bytes(cfg, P, P_tgt, cap2_levels):
+    """SURVEY.md §8d 'algorithmic (compulsory) bytes per step'."""
+    B, O = cfg.batch_size, 400
+    L = cap2_levels
+    rows = B * (8 * O + 17)
+    sample = B * (4 * L + 4 + 12)
+    wb = B * 4 + 2 * B * (4 + 12 * L)
+    return rows + sample + wb + 24 * P + 4 * P_tgt + 4 * B + 4
+
+
+def kernel_flops(cfg, B, A=6):
+    T, Tn, E, K, H = cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples, 1024, 64, 128
+    per_row_fwd = 2 * K * E + 2 * E * H + 2 * H * A
+    n_next = 2 if (cfg.use_target_network and cfg.use_double_q_learning) else 1
+    rows_fwd = B * T + n_next * B * Tn
+    fl = {"iqn_tile_fwd_kernel": rows_fwd * per_row_fwd,
+          "iqn_bwd_kernel": B * T * 2 * E * (K + H + K + H)}
+    return fl
+
+
+def cpu_baseline(cfg, seconds=12.0):
+    """The CPU oracle port of the same step (C sum tree + n-step gather, torch-CPU TD update)."""
+    import contextlib
+    import io
+    from oracle import per_ref
+    from oracle.learner_ref import LearnerOracle
+    from tests import helpers as H
+    from prism_amd.config import derive
+    ccfg = derive(cfg, device="cpu")
+    cap = min(cfg.experience_replay_capacity, 100_000)
+    rng = np.random.default_rng(0)
+    rp = per_ref.ReplayOracle(cap, 400, cfg.n_step_returns_length, cfg.gamma, cfg.per_alpha, 0.5, use_per=True)
+    rp.obs[:] = rng.random((cap, 400), dtype=np.float32) < 0.1
+    rp.succ_obs[:] = rng.random((cap, 400), dtype=np.float32) < 0.1
+    rp.reward[:] = rng.standard_normal(cap).astype(np.float32)
+    rp.action[:] = rng.integers(0, 6, cap)
+    done = rng.random(cap) < 0.017
+    rp.flags[:] = done * 1 + (~done) * 4
+    link = np.arange(cap) + 8
+    rp.link[:] = np.where((link < cap) & ~done, link, -1)
+    rp.length = cap
+    prio = (np.abs(rng.standard_normal(cap)) ** 0.5 + 1e-8).astype(np.float32)
+    rp.sampler.sum_tree.update(np.arange(cap), prio)
+    rp.sampler.min_tree.update(np.arange(cap), prio)
+    torch.manual_seed(cfg.seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sd, tgt = H.build_init_state(ccfg, cfg.seed)
+    orc = LearnerOracle(sd, H.spec_from_config(ccfg), tgt)
+    B, T, Tn = cfg.batch_size, cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples
+    n_tau = 1 + (1 if (not cfg.use_target_network or cfg.use_double_q_learning) else 0) + \
+        (1 if cfg.use_target_network else 0)
+
+    def one():
+        mass = rp.sampler.draw_mass(cap, B)
+        idx, w, _, _ = rp.sampler.sample(cap, mass)
+        g = rp.gather(idx)
+        batch = dict(obs=torch.from_numpy(g["obs"]).view(B, 10, 10, 4), next_obs=torch.from_numpy(g["next_obs"]).view(B, 10, 10, 4),
+                     reward=torch.from_numpy(g["reward"]), nonterminal=torch.from_numpy(g["nonterminal"].astype(bool)),
+                     gamma=torch.from_numpy(g["gamma"]), action=torch.from_numpy(g["action"]))
+        taus = [torch.rand(T * B, 1)] + [torch.rand(Tn * B, 1) for _ in range(n_tau - 1)]
+        td = orc.update(batch, torch.from_numpy(w), taus)
+        rp.sampler.update_priority(idx, td.abs().numpy())
+
+    for _ in range(3):
+        one()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} steps of the same workload (B={B}, replay {cap}) in {dt:.1f} s: C sum-tree sample + "
+                      f"n-step gather + torch-CPU TD update + priority writeback"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i]; 2 = the metric's config")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        pg = dist.group.WORLD
+
+    from prism_amd import _native as N
+    from prism_amd.config import baseline_config
+    from prism_amd.learner import Learner
+    from prism_amd.synthetic import fill_replay
+    import contextlib
+    import io
+
+    cfg = baseline_config(args.config, device=dev)
+    if args.config == 4:
+        cfg.experience_replay_capacity = 10_000_000 // world
+    cfg.per_seed_offset = rank
+    cfg.hip_graph = not args.no_graph
+    learner = Learner()
+    with contextlib.redirect_stdout(io.StringIO()):
+        learner.configure(cfg, obs_shape=(10, 10, 4), n_actions=6, process_group=pg)
+    learner.time_phases = False
+    buf, agent = learner.experience_buffer, learner.agent
+    buf.seed = cfg.seed + 7919 * rank
+    agent.seed = cfg.seed + 104729 * rank
+    fill_replay(buf, buf.capacity, seed=rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    L = N.lib()
+    for _ in range(args.warmup):
+        learner.step()
+    sync()
+    import ctypes
+    ms = (ctypes.c_double * N.N_KERNEL_IDS)()
+    cnt = (ctypes.c_int64 * N.N_KERNEL_IDS)()
+    L.prism_profile_collect(ms, cnt)
+    for i in range(N.N_KERNEL_IDS):
+        ms[i], cnt[i] = 0.0, 0
+    pe = max(1, args.profile_every)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        if i % pe == pe - 1:
+            L.prism_profile_enable(1)
+            learner.step(eager=True)
+            L.prism_profile_enable(0)
+        else:
+            learner.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    L.prism_profile_collect(ms, cnt)
+
+    if rank == 0:
+        kern = {}
+        for i in range(N.N_KERNEL_IDS):
+            if cnt[i]:
+                kern[L.prism_profile_kernel_name(i).decode()] = ms[i] / cnt[i] * 1e3     # us per launch
+        fl = kernel_flops(cfg, cfg.batch_size)
+        dom = max(fl, key=lambda k: kern.get(k, 0.0)) if kern else None
+        roof = None
+        P = agent.flat.numel()
+        P_tgt = P if cfg.use_target_network else 0
+        levels = int(np.log2(buf.tree_capacity))
+        abytes = algorithmic_bytes(cfg, P, P_tgt, levels)
+        step_s = elapsed / args.steps
+        if dom and kern.get(dom):
+            ach = fl[dom] / (kern[dom] * 1e-6) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(f"c{args.config}", {}).get(dom)
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "flops_per_launch": fl[dom], "us_per_launch": round(kern[dom], 3),
+                    "kernel_us": {k: round(v, 3) for k, v in kern.items()},
+                    "step_hbm": {"algorithmic_bytes": abytes, "achieved_GBps": round(abytes / step_s / 1e9, 2),
+                                 "peak_GBps": HBM_PEAK_GBS, "frac": round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 5)},
+                    "step_mfma_frac": round(sum(fl.values()) / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        out = {"metric": "learner grad-steps/sec, IQN+PER batch=256, 1/2/4/8 MI355X" if args.config == 2
+               else f"learner grad-steps/sec, BASELINE configs[{args.config}]",
+               "value": round(args.steps * world / elapsed, 2), "unit": "steps/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": f"configs[{args.config}]: " + ["DQN + uniform replay, batch=32",
+                                                                     "DQN + PER, batch=256",
+                                                                     "IQN (N_tau=8) + PER + 3-step returns, batch=256",
+                                                                     "IDS + IQN + LayerNorm + 3-step + target net, batch=512",
+                                                                     "full default, 10M-transition replay sharded"][args.config],
+                          "batch_per_gpu": cfg.batch_size, "global_batch": cfg.batch_size * world,
+                          "replay_capacity_per_gpu": buf.capacity, "obs": "10x10x4 fp32", "n_actions": 6,
+                          "parallelism": f"dp{world}", "hip_graph": bool(getattr(learner, "_graph", None))},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

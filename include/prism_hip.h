@@ -235,6 +235,20 @@ int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream)
 int prism_sync_target(float *target_params, const float *params, int64_t n_params,
                       prism_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
+ * roofline figure; off by default, adds two event records per instrumented launch).
+ * Kernel ids: 0 embed, 1 tile_fwd, 2 loss, 3 bwd, 4 small, 5 reduce, 6 clip_adam, 7 per_sample,
+ * 8 gather, 9 per_update, 10 q_fwd, 11 q_bwd.
+ * ------------------------------------------------------------------------------------------ */
+#define PRISM_N_KERNEL_IDS 16
+/* on != 0: instrument every launch issued by the calling thread until switched off */
+int prism_profile_enable(int on);
+/* host: synchronises the recorded events, ADDS elapsed milliseconds and launch counts per kernel id
+ * into ms_sum[PRISM_N_KERNEL_IDS] / count[PRISM_N_KERNEL_IDS], and recycles the events. */
+int prism_profile_collect(double *ms_sum, int64_t *count);
+const char *prism_profile_kernel_name(int id);
+
 #ifdef __cplusplus
 }
 #endif

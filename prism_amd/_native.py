@@ -88,7 +88,11 @@ SIGNATURES = {
     "prism_learner_fwd_bwd": (ctypes.c_int, [_P(LearnerDesc), c_vp]),
     "prism_learner_clip_adam": (ctypes.c_int, [_P(LearnerDesc), c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),
+    "prism_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
 }
+N_KERNEL_IDS = 16
 
 _lib = None
 

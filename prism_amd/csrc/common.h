@@ -27,6 +27,24 @@ void set_error(const char *fmt, ...);
         }                                                                           \
     } while (0)
 
+// ---- optional HIP-event instrumentation (profile.hip) ----
+enum KernelId { K_EMBED = 0, K_TILE_FWD, K_LOSS, K_BWD, K_SMALL, K_REDUCE, K_CLIP_ADAM, K_PER_SAMPLE, K_GATHER,
+                K_PER_UPDATE, K_Q_FWD, K_Q_BWD };
+extern thread_local int g_profile_on;
+void profile_begin(int kernel_id, hipStream_t stream);
+void profile_end(int kernel_id, hipStream_t stream);
+struct ProfileScope {
+    int id;
+    hipStream_t s;
+    bool on;
+    ProfileScope(int id_, hipStream_t s_) : id(id_), s(s_), on(g_profile_on != 0) {
+        if (on) profile_begin(id, s);
+    }
+    ~ProfileScope() {
+        if (on) profile_end(id, s);
+    }
+};
+
 constexpr int WAVE = 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

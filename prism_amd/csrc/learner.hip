@@ -265,18 +265,36 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         attr_set = true;
     }
 
-    hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4), dim3(256), 0, stream, a);
-    PRISM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
-    PRISM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64), 0, stream, a);
-    PRISM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
-    PRISM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(iqn_small_kernel, dim3(16 * CONV_CHUNKS + 1), dim3(1024), 0, stream, a);
-    PRISM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(iqn_reduce_kernel, dim3(REDUCE_BLOCKS), dim3(256), 0, stream, a);
-    PRISM_CHECK_LAUNCH();
+    {
+        ProfileScope ps_(K_EMBED, stream);
+        hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4), dim3(256), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_TILE_FWD, stream);
+        hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_LOSS, stream);
+        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_BWD, stream);
+        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_SMALL, stream);
+        hipLaunchKernelGGL(iqn_small_kernel, dim3(16 * CONV_CHUNKS + 1), dim3(1024), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_REDUCE, stream);
+        hipLaunchKernelGGL(iqn_reduce_kernel, dim3(REDUCE_BLOCKS), dim3(256), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
     if (ld->dbg_z) {
         const size_t R = (size_t)B * d.n_tau, Rn = (size_t)B * d.n_tau_next, A = d.n_actions;
         hipMemcpyAsync(ld->dbg_z, a.ws.zcur, R * A * 4, hipMemcpyDeviceToDevice, stream);
@@ -323,7 +341,10 @@ extern "C" int prism_learner_clip_adam(const prism_learner_desc *ld, prism_strea
     }
     int blocks = (int)((a.n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
-    PRISM_CHECK_LAUNCH();
+    {
+        ProfileScope ps_(K_CLIP_ADAM, stream);
+        hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
     return PRISM_OK;
 }

@@ -437,9 +437,12 @@ extern "C" int prism_per_sample(const prism_replay_desc *rp, int64_t size, int32
     if (rc) return rc;
     PRISM_CHECK_ARG(size > 0 && size <= rp->capacity, "size must be in (0, capacity] (empty storage)");
     PRISM_CHECK_ARG(batch > 0 && out_index && out_weight, "batch/out");
-    hipLaunchKernelGGL(per_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, *rp, size,
-                       batch, mass, seed, offset, beta, out_index, out_weight);
-    PRISM_CHECK_LAUNCH();
+    {
+        ProfileScope ps_(K_PER_SAMPLE, (hipStream_t)stream);
+        hipLaunchKernelGGL(per_sample_kernel, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, *rp, size,
+                           batch, mass, seed, offset, beta, out_index, out_weight);
+        PRISM_CHECK_LAUNCH();
+    }
     return PRISM_OK;
 }
 
@@ -460,9 +463,12 @@ extern "C" int prism_replay_gather(const prism_replay_desc *rp, const int64_t *i
     PRISM_CHECK_ARG(batch > 0 && index && out_obs && out_next_obs && out_reward && out_nonterminal && out_gamma &&
                         out_action,
                     "batch/out");
-    hipLaunchKernelGGL(replay_gather_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, *rp, index, batch,
-                       out_obs, out_next_obs, out_reward, out_nonterminal, out_gamma, out_action);
-    PRISM_CHECK_LAUNCH();
+    {
+        ProfileScope ps_(K_GATHER, (hipStream_t)stream);
+        hipLaunchKernelGGL(replay_gather_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, *rp, index, batch,
+                           out_obs, out_next_obs, out_reward, out_nonterminal, out_gamma, out_action);
+        PRISM_CHECK_LAUNCH();
+    }
     return PRISM_OK;
 }
 
@@ -472,9 +478,12 @@ extern "C" int prism_per_update(const prism_replay_desc *rp, const int64_t *inde
     if (rc) return rc;
     PRISM_CHECK_ARG(batch > 0 && index && priority, "batch/index/priority");
     const int threads = batch >= 1024 ? 1024 : ((batch + 127) / 128) * 128;
-    hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, *rp, index, priority, batch,
-                       alpha, eps, take_abs);
-    PRISM_CHECK_LAUNCH();
+    {
+        ProfileScope ps_(K_PER_UPDATE, (hipStream_t)stream);
+        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, *rp, index, priority, batch,
+                           alpha, eps, take_abs);
+        PRISM_CHECK_LAUNCH();
+    }
     return PRISM_OK;
 }
 
