@@ -222,7 +222,7 @@ def main():
                                                                      "full default, 10M-transition replay sharded"][args.config],
                           "batch_per_gpu": cfg.batch_size, "global_batch": cfg.batch_size * world,
                           "replay_capacity_per_gpu": buf.capacity, "obs": "10x10x4 fp32", "n_actions": 6,
-                          "parallelism": f"dp{world}", "hip_graph": bool(getattr(learner, "_graph", None))},
+                          "parallelism": f"dp{world}", "hip_graph": any(isinstance(g, tuple) for g in getattr(agent, "_graphs", {}).values())},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

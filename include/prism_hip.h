@@ -182,7 +182,7 @@ typedef struct prism_learner_desc {
     prism_model_dims dims;
     prism_param_offsets off;
     int32_t batch;            /* B                                                           */
-    int32_t reserved0;
+    int32_t embed_done;       /* != 0: prism_step_front already produced the embeddings for this batch */
     /* parameters and optimizer state, flat fp32 [n_params] */
     float *params;
     const float *target_params; /* NULL when !has_target                                     */
@@ -205,12 +205,16 @@ typedef struct prism_learner_desc {
     const float *tau_next_target; /* [T'*B] used when has_target                              */
     float *tau_out;           /* [3][max(T,T')*B] or NULL                                     */
     uint64_t seed, offset;
+    uint64_t *rng_counters;   /* optional device [2] {PER draws, tau draws} added to the immediate offsets
+                                 and advanced by prism_step_back (lets a captured hipGraph draw fresh
+                                 numbers on every replay); NULL = immediate offsets only              */
     /* outputs */
     float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */
     float *out_q_loss;        /* [B] or NULL  (Agent._static_q_loss)                          */
     float *out_td;            /* [B]          (td_errors, composite_model.py:135-142)         */
     float *out_scalars;       /* [8] {total loss, mean dl*w, mean ql*w, grad norm, theil, clip coef, -, -} */
     float *dbg_z;             /* optional [ (T+T')*B*A ] quantile estimates (tests) or NULL    */
+    void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][16] uint64 shader-clock stamps, else NULL */
     void *workspace;          /* >= prism_learner_workspace_bytes()                           */
     size_t workspace_bytes;
     prism_adam_hyper hyper;
@@ -231,6 +235,26 @@ int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream);
  * agent_factory.py:44-47) over the flat buffers; adam_step += 1. */
 int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused hot path — one Learner iteration (prism/learner.py:95-125) in six launches:
+ *   prism_step_front                        PER sample + n-step gather + conv embed (+ LayerNorm helpers)
+ *   prism_learner_fwd_bwd (embed_done = 1)  quantile forward tiles, loss, column-sliced backward, post
+ *   [RCCL all-reduce of ld->grads when data-parallel]
+ *   prism_step_back                         clip + Adam, priority writeback with |td|, RNG counters
+ * Results are identical to per_sample -> replay_gather -> fwd_bwd -> clip_adam -> per_update.
+ * ------------------------------------------------------------------------------------------ */
+/* TimestepBuffer.sample (timestep_buffer.py:35-51) fused with the embedding of both observations.
+ * Writes the minibatch into ld->obs/next_obs/reward/nonterminal/gamma/action (the static batch),
+ * out_index [B] int64 and out_weight [B] (set ld->per_weights = out_weight to use them).
+ * rp->sum_tree == NULL selects uniform replay. */
+int prism_step_front(const prism_learner_desc *ld, const prism_replay_desc *rp, int64_t size,
+                     const float *mass, uint64_t seed, uint64_t offset, float beta,
+                     int64_t *out_index, float *out_weight, prism_stream_t stream);
+
+/* prism_learner_clip_adam + prism_per_update(index, |ld->out_td|) in one launch. */
+int prism_step_back(const prism_learner_desc *ld, const prism_replay_desc *rp, const int64_t *index,
+                    float alpha, float eps, prism_stream_t stream);
+
 /* Agent.sync_target_model (agent.py:149-152): target := online (device-to-device copy). */
 int prism_sync_target(float *target_params, const float *params, int64_t n_params,
                       prism_stream_t stream);
@@ -238,8 +262,8 @@ int prism_sync_target(float *target_params, const float *params, int64_t n_param
 /* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure; off by default, adds two event records per instrumented launch).
- * Kernel ids: 0 embed, 1 tile_fwd, 2 loss, 3 bwd, 4 small, 5 reduce, 6 clip_adam, 7 per_sample,
- * 8 gather, 9 per_update, 10 q_fwd, 11 q_bwd.
+ * Kernel ids: 0 embed, 1 tile_fwd, 2 loss, 3 bwd, 4 post, 5 front, 6 clip_adam, 7 per_sample,
+ * 8 gather, 9 per_update, 10 back, 11 q_fwd, 12 q_bwd.
  * ------------------------------------------------------------------------------------------ */
 #define PRISM_N_KERNEL_IDS 16
 /* on != 0: instrument every launch issued by the calling thread until switched off */

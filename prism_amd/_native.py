@@ -54,15 +54,15 @@ class AdamHyper(ctypes.Structure):
 
 
 class LearnerDesc(ctypes.Structure):
-    _fields_ = [("dims", ModelDims), ("off", ParamOffsets), ("batch", c_i32), ("reserved0", c_i32),
+    _fields_ = [("dims", ModelDims), ("off", ParamOffsets), ("batch", c_i32), ("embed_done", c_i32),
                 ("params", c_vp), ("target_params", c_vp), ("grads", c_vp), ("adam_m", c_vp), ("adam_v", c_vp),
                 ("adam_step", c_vp),
                 ("obs", c_vp), ("next_obs", c_vp), ("reward", c_vp), ("nonterminal", c_vp), ("gamma", c_vp),
                 ("action", c_vp), ("per_weights", c_vp),
                 ("tau_cur", c_vp), ("tau_next_online", c_vp), ("tau_next_target", c_vp), ("tau_out", c_vp),
-                ("seed", c_u64), ("offset", c_u64),
+                ("seed", c_u64), ("offset", c_u64), ("rng_counters", c_vp),
                 ("out_dist_loss", c_vp), ("out_q_loss", c_vp), ("out_td", c_vp), ("out_scalars", c_vp),
-                ("dbg_z", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
+                ("dbg_z", c_vp), ("dbg_stamps", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
                 ("hyper", AdamHyper)]
 
 
@@ -87,6 +87,9 @@ SIGNATURES = {
     "prism_learner_supported": (ctypes.c_int, [_P(ModelDims), c_i32]),
     "prism_learner_fwd_bwd": (ctypes.c_int, [_P(LearnerDesc), c_vp]),
     "prism_learner_clip_adam": (ctypes.c_int, [_P(LearnerDesc), c_vp]),
+    "prism_step_front": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_i64, c_vp, c_u64, c_u64, c_f32, c_vp, c_vp,
+                                         c_vp]),
+    "prism_step_back": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_vp, c_f32, c_f32, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),

@@ -219,7 +219,9 @@ class HipAgent:
         d.out_td, d.out_scalars = self.out_td.data_ptr(), self.scalars.data_ptr()
         d.workspace, d.workspace_bytes = self.workspace.data_ptr(), ws_bytes
         d.seed = self.seed
+        self.rng_counters = torch.zeros(2, dtype=torch.int64, device=dev)     # {PER draws, tau draws}
         self._desc, self._B = d, B
+        self._graphs = {}
 
     def _set_hyper(self):
         g, h = self.optimizer.param_groups[0], self._desc.hyper
@@ -274,6 +276,7 @@ class HipAgent:
             if self.dims.has_target:
                 d.tau_next_target = next(it).data_ptr()
         d.offset = self._draw_offset
+        d.rng_counters, d.embed_done = None, 0
         self._draw_offset += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * B
         self._set_hyper()
         L = N.lib()
@@ -288,6 +291,95 @@ class HipAgent:
         self._static_q_loss = self.out_ql if self.dims.n_heads > 0 else None
         self.n_updates += 1
         return self.out_td
+
+    # ------------------------------------------------------------------ fused hot path
+    def _bind_fused(self, buf):
+        """Point the descriptor at the buffer's static batch / IS weights (stable device addresses)."""
+        B = int(buf._index.shape[0])
+        if self._B != B:
+            self._prepare(B)
+        d = self._desc
+        d.obs, d.next_obs = buf._obs.data_ptr(), buf._next_obs.data_ptr()
+        d.reward, d.nonterminal = buf._reward.data_ptr(), buf._nonterminal.data_ptr()
+        d.gamma, d.action = buf._gamma.data_ptr(), buf._action.data_ptr()
+        d.per_weights = buf._weight.data_ptr() if buf.use_per else None
+        d.tau_cur = d.tau_next_online = d.tau_next_target = None
+        self._set_hyper()
+        return d
+
+    def _launch_fused(self, buf, d, part="all"):
+        L, st = N.lib(), N.current_stream_handle
+        rp = ctypes.byref(buf._desc)
+        if part in ("all", "front"):
+            d.embed_done = 1
+            N.check(L.prism_step_front(ctypes.byref(d), rp, buf._size, None, buf.seed, d.offset,
+                                       buf.buffer._sampler._beta, N.ptr(buf._index), N.ptr(buf._weight), st()),
+                    "prism_step_front")
+            N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), st()), "prism_learner_fwd_bwd")
+            d.embed_done = 0
+        if part == "all" and self.world > 1:
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+        if part in ("all", "back"):
+            smp = buf.buffer._sampler
+            N.check(L.prism_step_back(ctypes.byref(d), rp, N.ptr(buf._index), smp._alpha, smp._eps, st()),
+                    "prism_step_back")
+
+    def step_fused(self, buf, eager=False, use_graph=True):
+        """Sample + update + priority writeback as six launches (prism_step_front, fwd_bwd,
+        prism_step_back); replayed from a hipGraph when the replay is full (its size is baked into
+        the captured launches) and the RNG counters live on the device."""
+        if self.tau_rng != "philox" or buf.mass_rng != "philox":
+            raise RuntimeError("fused step draws its random numbers in-kernel (per_mass_rng/tau_rng = 'philox')")
+        if buf._index is None or buf._index.shape[0] != buf.buffer._batch_size:
+            buf._alloc_batch(buf.buffer._batch_size)
+        d = self._bind_fused(buf)
+        d.rng_counters = self.rng_counters.data_ptr()
+        d.offset = 0
+        graphable = use_graph and not eager and buf._size == buf.capacity
+        with torch.cuda.device(self.device):
+            if not graphable:
+                self._launch_fused(buf, d)
+            else:
+                key = (id(buf), buf._size, self.world)
+                g = self._graphs.get(key)
+                if g is None:
+                    self._launch_fused(buf, d)                  # first full-buffer step runs eagerly
+                    self._graphs[key] = "warm"
+                elif g == "warm":
+                    torch.cuda.current_stream().synchronize()
+                    self._graphs[key] = self._capture(buf, d)   # capture, then replay once = this step
+                else:
+                    self._replay(g, buf, d)
+        self._static_total_loss = self.scalars[0]
+        self._static_distribution_loss = self.out_dl if self.dims.use_iqn else None
+        self._static_q_loss = self.out_ql if self.dims.n_heads > 0 else None
+        self.n_updates += 1
+        return self.out_td
+
+    def _capture(self, buf, d):
+        if self.world == 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch_fused(buf, d)
+            g.replay()
+            return (g,)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._launch_fused(buf, d, "front")
+        g1.replay()
+        torch.distributed.all_reduce(self.grads, group=self.pg)
+        with torch.cuda.graph(g2):
+            self._launch_fused(buf, d, "back")
+        g2.replay()
+        return (g1, g2)
+
+    def _replay(self, g, buf, d):
+        if len(g) == 1:
+            g[0].replay()
+        else:
+            g[0].replay()
+            torch.distributed.all_reduce(self.grads, group=self.pg)
+            g[1].replay()
 
     @torch.no_grad()
     def forward(self, obs):

@@ -34,6 +34,8 @@ constexpr float PI_F = 3.14159274101257324f;  // fp32(np.pi), the scalar torch m
 
 struct IqnPass {
     const float *params;  // weight set for this pass (online or target flat buffer)
+    const float *wphi_pk; // fragment-packed copies of phi.weight / trunk weight of that set (pack_weights_block)
+    const float *w1_pk;
     const float *e;       // [B][E] embedded observations feeding this pass
     const float *tau_in;  // [T*B] tau-major, or NULL -> Philox
     float *z_out;         // [B*T][A] sample-major
@@ -45,19 +47,19 @@ struct IqnPass {
 
 struct IqnWs {           // workspace pointers (device)
     float *e_cur, *e_next, *uv;
+    float *wpk[2];       // [online, target] fragment-packed {phi_w (E*K) | w1 (H*E)}
     float *cosb, *mu1, *rstd1, *pre1, *xhat2, *rstd2;
     float *zcur, *zon, *ztg;
     float *dq, *c1, *c2, *dpre1, *Sb, *Pb, *Db, *lossw;
     float *de_iqn;
     float *slabs;        // [n_chunks][SLAB]
-    float *convpart;     // [16][CONV_CHUNKS][9C+1]
+    float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
     float *normpart;     // [NORM_SLOTS]
-    unsigned int *ticket;
+    unsigned int *ticket;   // [4] {adam, conv, -, -}, zero-initialised by the caller, self-resetting
 };
 
 constexpr int SLAB = E_DIM * K_BASIS + E_DIM + E_DIM + E_DIM + H_DIM * E_DIM;  // phi_w|phi_b|ln1_g|ln1_b|w1
-constexpr int CONV_CHUNKS = 16;
-constexpr int NORM_SLOTS = 1024;
+constexpr int NORM_SLOTS = 1280;
 
 struct IqnArgs {
     IqnPass pass[3];
@@ -65,6 +67,8 @@ struct IqnArgs {
     int B, A, C, T, Tn;
     int n_chunks;          // row chunks of the backward
     int has_target, double_q, propagate_grad;
+    int dbg;               // experiment switches (PRISM_DBG env), 0 in production
+    unsigned long long *stamps;   // diagnostic builds only: [block][16] shader-clock stamps (dbg & 8)
     float huber_k, dist_w;
     prism_param_offsets off;
     const float *params;
@@ -73,6 +77,7 @@ struct IqnArgs {
     const uint8_t *nonterminal;
     const int64_t *action;
     uint64_t seed, offset;
+    const uint64_t *rng;   // device counters {PER draws, tau draws} or NULL
     float *tau_out;        // [3][maxT*B] or NULL
     int maxT;
     float *out_dl, *out_td, *out_scalars;
@@ -81,46 +86,63 @@ struct IqnArgs {
 };
 
 // ------------------------------------------------------------------------------------------
+// Fragment-packed weight copies.  Reading the canonical [n][k] matrices in MFMA B-operand shape
+// touches 16 rows 4 KB apart per wave instruction and streams at ~16 B/clk/CU; the same bytes laid
+// out so that every wave instruction of tile_fwd reads 1 KB contiguous stream at 31-51 B/clk/CU
+// (tools/ubench/l2_stream.hip).  The copies are rebuilt from the canonical parameters by extra
+// blocks of the embed/front launch every step (0.8 MB, off the critical path), so they can never go
+// stale.  Layouts (float4 index):
+//   phi : [(wave w = n>>7) * 8 + (nt = (n>>4)&7)] * 4 + q   ][lane = g*16 + li]  = Wphi[n = 128w+16nt+li][16q+4g .. +3]
+//   w1  : [(wave w = k>>7) * 8 + (nt = h>>4)    ] * 8 + q   ][lane = g*16 + li]  = W1[h = 16nt+li][128w+16q+4g .. +3]
+// ------------------------------------------------------------------------------------------
+constexpr int PACK_FLOATS = E_DIM * K_BASIS + H_DIM * E_DIM;
+constexpr int PACK_BLOCKS = PACK_FLOATS / 4 / 256;     // one float4 per thread, 256 threads: 192 blocks
+
+__device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, const prism_param_offsets &off,
+                                                   float *__restrict__ pk, int blk, int tid) {
+    const int p4 = blk * 256 + tid;              // packed float4 index
+    const int lane = p4 & 63, li = lane & 15, g = lane >> 4;
+    const float *src;
+    if (p4 < E_DIM * K_BASIS / 4) {
+        const int q = (p4 >> 6) & 3, nt = (p4 >> 8) & 7, w = p4 >> 11;
+        src = P + off.phi_w + (int64_t)(128 * w + 16 * nt + li) * K_BASIS + 16 * q + 4 * g;
+    } else {
+        const int r = p4 - E_DIM * K_BASIS / 4;
+        const int q = (r >> 6) & 7, nt = (r >> 9) & 7, w = r >> 12;
+        src = P + off.iqn_w1 + (int64_t)(16 * nt + li) * E_DIM + 128 * w + 16 * q + 4 * g;
+    }
+    reinterpret_cast<float4 *>(pk)[p4] = *reinterpret_cast<const float4 *>(src);
+}
+
+// ------------------------------------------------------------------------------------------
 // embed: blocks [0,B) conv(obs) online; [B,2B) conv(next_obs) with target-or-online weights;
 //        blocks [2B, 2B + H/4) compute u,v.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
-    __shared__ float s_obs[1024];
-    __shared__ float s_w[16 * 16 * 9];
-    __shared__ float s_b[16];
-    const int B = a.B, C = a.C;
-    const int blk = blockIdx.x, tid = threadIdx.x;
-    if (blk >= 2 * B) {
-        // u[h] = sum_n W1[h][n] g1[n],  v[h] = sum_n W1[h][n] beta1[n]   (one wave per h)
-        const int h = (blk - 2 * B) * 4 + (tid >> 6), lane = tid & 63;
-        const float *W1 = a.params + a.off.iqn_w1 + (int64_t)h * E_DIM;
-        const float *g1 = a.params + a.off.iqn_ln1_g, *b1 = a.params + a.off.iqn_ln1_b;
-        float su = 0.f, sv = 0.f;
-        for (int n = lane * 4; n < E_DIM; n += 256) {
-            const float4 w = *reinterpret_cast<const float4 *>(W1 + n);
-            const float4 g = *reinterpret_cast<const float4 *>(g1 + n);
-            const float4 bb = *reinterpret_cast<const float4 *>(b1 + n);
-            su += w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
-            sv += w.x * bb.x + w.y * bb.y + w.z * bb.z + w.w * bb.w;
-        }
-        su = wave_sum(su);
-        sv = wave_sum(sv);
-        if (lane == 0) {
-            a.ws.uv[h] = su;
-            a.ws.uv[H_DIM + h] = sv;
-        }
-        return;
+// u[h] = sum_n W1[h][n] g1[n],  v[h] = sum_n W1[h][n] beta1[n]   (one wave per h)
+__device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int h, int lane) {
+    const float *W1 = a.params + a.off.iqn_w1 + (int64_t)h * E_DIM;
+    const float *g1 = a.params + a.off.iqn_ln1_g, *b1 = a.params + a.off.iqn_ln1_b;
+    float su = 0.f, sv = 0.f;
+#pragma unroll
+    for (int n = lane * 4; n < E_DIM; n += 256) {
+        const float4 w = *reinterpret_cast<const float4 *>(W1 + n);
+        const float4 g = *reinterpret_cast<const float4 *>(g1 + n);
+        const float4 bb = *reinterpret_cast<const float4 *>(b1 + n);
+        su += w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
+        sv += w.x * bb.x + w.y * bb.y + w.z * bb.z + w.w * bb.w;
     }
-    const bool is_next = blk >= B;
-    const int b = is_next ? blk - B : blk;
-    const float *P = (is_next && a.has_target) ? a.target_params : a.params;
-    const float *src = (is_next ? a.next_obs : a.obs) + (int64_t)b * 100 * C;
-    float *dst = (is_next ? a.ws.e_next : a.ws.e_cur) + (int64_t)b * E_DIM;
-    for (int i = tid; i < 100 * C; i += 256) s_obs[i] = src[i];
-    for (int i = tid; i < 16 * C * 9; i += 256) s_w[i] = P[a.off.conv_w + i];
-    if (tid < 16) s_b[tid] = P[a.off.conv_b + tid];
-    __syncthreads();
-    for (int n = tid; n < E_DIM; n += 256) {
+    su = wave_sum(su);
+    sv = wave_sum(sv);
+    if (lane == 0) {
+        a.ws.uv[h] = su;
+        a.ws.uv[H_DIM + h] = sv;
+    }
+}
+
+// Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS
+__device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
+                                                float *__restrict__ dst, int tid, int nthreads) {
+    for (int n = tid; n < E_DIM; n += nthreads) {
         const int c = n >> 6, y = (n >> 3) & 7, x = n & 7;
         float acc = s_b[c];
         const float *w = s_w + c * C * 9;
@@ -134,18 +156,59 @@ __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
+    __shared__ float s_obs[1024];
+    __shared__ float s_w[16 * 10 * 9];
+    __shared__ float s_b[16];
+    const int B = a.B, C = a.C;
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk >= 2 * B + H_DIM / 4) {
+        const int pb = blk - (2 * B + H_DIM / 4);
+        if (pb < PACK_BLOCKS) pack_weights_block(a.params, a.off, a.ws.wpk[0], pb, tid);
+        else pack_weights_block(a.target_params, a.off, a.ws.wpk[1], pb - PACK_BLOCKS, tid);
+        return;
+    }
+    if (blk >= 2 * B) {
+        iqn_uv_block(a, (blk - 2 * B) * 4 + (tid >> 6), tid & 63);
+        return;
+    }
+    const bool is_next = blk >= B;
+    const int b = is_next ? blk - B : blk;
+    const float *P = (is_next && a.has_target) ? a.target_params : a.params;
+    const float *src = (is_next ? a.next_obs : a.obs) + (int64_t)b * 100 * C;
+    float *dst = (is_next ? a.ws.e_next : a.ws.e_cur) + (int64_t)b * E_DIM;
+#pragma unroll 4
+    for (int i = tid; i < 100 * C; i += 256) s_obs[i] = src[i];
+#pragma unroll 4
+    for (int i = tid; i < 16 * C * 9; i += 256) s_w[i] = P[a.off.conv_w + i];
+    if (tid < 16) s_b[tid] = P[a.off.conv_b + tid];
+    __syncthreads();
+    conv_embed_rows(s_obs, s_w, s_b, C, dst, tid, 256);
+}
+
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight
+// (a plain __syncthreads() also waits for vmcnt(0), which would serialise every weight prefetch).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define PRISM_STAMP(k)                                                                     \
+    do {                                                                                   \
+        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------
 // tile_fwd: 512 threads = 8 waves, one 16-row tile per workgroup.
 // ------------------------------------------------------------------------------------------
-constexpr int TILE_FWD_LDS_FLOATS = 16 * YS + 16 * CS + 16 * HS + 64;
+constexpr int PS = H_DIM + 4;   // row stride of the per-wave trunk partials
+constexpr int TILE_FWD_LDS_FLOATS = 16 * YS + 16 * CS + 16 * HS + 64 + 8 * 16 * PS;
 
 __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ytile = smem;
     float *cost = ytile + 16 * YS;
     float *h1 = cost + 16 * CS;
-    float *rowf = h1 + 16 * HS;                 // [0,16) tau, [16,32) mu, [32,48) rstd
+    float *rowf = h1 + 16 * HS;                 // [0,16) tau
     int *rowb = reinterpret_cast<int *>(rowf + 48);  // [16] sample of each row
+    float *part = rowf + 64;                    // [8 waves][16 rows][PS] K-split partials of the trunk GEMM
 
     int tile = blockIdx.x, pi = 0;
     while (pi < a.n_pass - 1 && tile >= a.pass[pi].n_tiles) {
@@ -159,6 +222,29 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     const int r0 = tile * 16;
     const float *P = ps.params;
 
+    // Weights do not depend on anything computed here: put the whole phi B operand of this wave
+    // (8 column tiles x K = 64) in flight before the first barrier.
+    PRISM_STAMP(0);
+    const float *bphi = P + a.off.phi_b;
+    float4 bq[8][4];       // [tile][q]: B[k = 16q + 4g + jj][n = 128w + 16nt + li], 1 KB contiguous per wave load
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(ps.wphi_pk) + (size_t)w * 8 * 4 * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bq[nt][q] = (a.dbg & 2) ? float4{1.f, 2.f, 3.f, 4.f} : src[(nt * 4 + q) * 64];
+    }
+
+    // phi epilogue operands (bias, embedded observation of the row group's sample): also early
+    const float *erow = ps.e + (int64_t)((r0 + 4 * g) / T) * E_DIM;   // rows 4g..4g+3 share a sample (T % 4 == 0)
+    float pb_[8], pe_[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        pb_[nt] = bphi[w * 128 + nt * 16 + li];
+        pe_[nt] = erow[w * 128 + nt * 16 + li];
+    }
+
     if (tid < 16) {
         const int r = r0 + tid, b = r / T, t = r - b * T;
         float tau;
@@ -167,14 +253,14 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
         } else {
             uint32_t rr[4];
             Philox ph(a.seed);
-            ph(a.offset + (uint64_t)((int64_t)t * B + b), 0x54415530ull + (uint64_t)ps.stream_id, rr);
+            ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)t * B + b), 0x54415530ull + (uint64_t)ps.stream_id, rr);
             tau = u32_to_unit_float(rr[0]);
         }
         if (a.tau_out) a.tau_out[(int64_t)ps.stream_id * a.maxT * B + (int64_t)t * B + b] = tau;
         rowf[tid] = tau;
         rowb[tid] = b;
     }
-    __syncthreads();
+    lds_barrier();
     // cos basis: c[m][k] = cos(tau * (k+1) * pi), two fp32 multiplies as torch does (iqn_model.py:90-92)
     for (int idx = tid; idx < 16 * K_BASIS; idx += 512) {
         const int m = idx >> 6, k = idx & 63;
@@ -183,49 +269,61 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
         cost[m * CS + k] = c;
         if (ps.save) a.ws.cosb[(int64_t)(r0 + m) * K_BASIS + k] = c;
     }
-    __syncthreads();
+    lds_barrier();
 
+    PRISM_STAMP(1);
+    // Trunk weights: wave w owns the K slice [128w, 128w+128) for ALL 128 outputs.  The first four
+    // output tiles' B operand is requested tile by tile WHILE the phi tiles are being consumed, so the
+    // weight stream never pauses between the two GEMMs.
+    const float4 *W1pk = reinterpret_cast<const float4 *>(ps.w1_pk) + (size_t)w * 8 * 8 * 64 + lane;
+    float4 bt[4][8];       // [ring slot][q]: B[k = 128w + 16q + 4g + jj][h = 16nt + li]
     // ---- phi GEMM (16 x 1024, K = 64) + bias + ReLU + Hadamard with e -> ytile ----------------
+    // two column tiles at a time: their MFMA chains interleave, so no chain waits on itself
     {
         float4 afr[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) afr[q] = *reinterpret_cast<const float4 *>(&cost[li * CS + 16 * q + 4 * g]);
-        const float *Wphi = P + a.off.phi_w, *bphi = P + a.off.phi_b;
-        const float *erow = ps.e + (int64_t)rowb[4 * g] * E_DIM;   // rows 4g..4g+3 share a sample (T % 4 == 0)
-        float4 bfr[4], bnx[4];
-        {
-            const float *src = Wphi + (int64_t)(w * 128 + li) * K_BASIS + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            const int n = w * 128 + nt * 16 + li;
-            if (nt < 7) {
-                const float *src = Wphi + (int64_t)(n + 16) * K_BASIS + 4 * g;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bnx[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-            }
-            const float bias = bphi[n], ev = erow[n];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int np = 0; np < 4; ++np) {
+            const int n0 = w * 128 + np * 32 + li, n1 = n0 + 16;
+            const float bias0 = pb_[2 * np], ev0 = pe_[2 * np], bias1 = pb_[2 * np + 1], ev1 = pe_[2 * np + 1];
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc = mfma16(afr[q].x, bfr[q].x, acc);
-                acc = mfma16(afr[q].y, bfr[q].y, acc);
-                acc = mfma16(afr[q].z, bfr[q].z, acc);
-                acc = mfma16(afr[q].w, bfr[q].w, acc);
+                acc0 = mfma16(afr[q].x, bq[2 * np][q].x, acc0);
+                acc1 = mfma16(afr[q].x, bq[2 * np + 1][q].x, acc1);
+                acc0 = mfma16(afr[q].y, bq[2 * np][q].y, acc0);
+                acc1 = mfma16(afr[q].y, bq[2 * np + 1][q].y, acc1);
+                acc0 = mfma16(afr[q].z, bq[2 * np][q].z, acc0);
+                acc1 = mfma16(afr[q].z, bq[2 * np + 1][q].z, acc1);
+                acc0 = mfma16(afr[q].w, bq[2 * np][q].w, acc0);
+                acc1 = mfma16(afr[q].w, bq[2 * np + 1][q].w, acc1);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ytile[(4 * g + r) * YS + n] = fmaxf(acc[r] + bias, 0.f) * ev;
+            for (int r = 0; r < 4; ++r) {
+                ytile[(4 * g + r) * YS + n0] = fmaxf(acc0[r] + bias0, 0.f) * ev0;
+                ytile[(4 * g + r) * YS + n1] = fmaxf(acc1[r] + bias1, 0.f) * ev1;
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[q] = bnx[q];
+            for (int q = 0; q < 8; ++q)     // one trunk tile per consumed phi pair
+                bt[np][q] = (a.dbg & 1) ? float4{1.f, 2.f, 3.f, 4.f} : W1pk[(np * 8 + q) * 64];
         }
     }
-    __syncthreads();
-
-    // ---- LayerNorm(1024): wave w owns rows 2w, 2w+1; normalise in place ------------------------
+    PRISM_STAMP(2);
+    float4 lng[4], lnb[4];      // LayerNorm(1024) affine for this lane's 16 columns: in flight across the barrier
     {
         const float *g1 = P + a.off.iqn_ln1_g, *be1 = P + a.off.iqn_ln1_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lng[i] = *reinterpret_cast<const float4 *>(g1 + (i * 64 + lane) * 4);
+            lnb[i] = *reinterpret_cast<const float4 *>(be1 + (i * 64 + lane) * 4);
+        }
+    }
+    lds_barrier();
+
+    PRISM_STAMP(3);
+    // ---- LayerNorm(1024): wave w owns rows 2w, 2w+1; normalise in place ------------------------
+    {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int m = 2 * w + rr;
@@ -248,8 +346,7 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = (i * 64 + lane) * 4;
-                const float4 gg = *reinterpret_cast<const float4 *>(g1 + n);
-                const float4 bb = *reinterpret_cast<const float4 *>(be1 + n);
+                const float4 gg = lng[i], bb = lnb[i];
                 float4 y;
                 y.x = x[i].x * rstd * gg.x + bb.x;
                 y.y = x[i].y * rstd * gg.y + bb.y;
@@ -263,45 +360,74 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---- trunk GEMM (16 x 128, K = 1024): wave w owns output columns 16w..16w+15 -------------
+    PRISM_STAMP(4);
+    // ---- trunk GEMM (16 x 128, K = 1024), K split over the 8 waves ------------------------------
     {
-        const float *brow = P + a.off.iqn_w1 + (int64_t)(16 * w + li) * E_DIM + 4 * g;
-        const float *arow = ytile + li * YS + 4 * g;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float4 breg[8];
+        float4 at[8];   // A fragments of this wave's K slice, reused by all 8 output tiles
 #pragma unroll
-        for (int i = 0; i < 8; ++i) breg[i] = *reinterpret_cast<const float4 *>(brow + 16 * i);
-        for (int qo = 0; qo < 8; ++qo) {
+        for (int q = 0; q < 8; ++q) at[q] = *reinterpret_cast<const float4 *>(&ytile[li * YS + 128 * w + 16 * q + 4 * g]);
+        float *mypart = part + w * 16 * PS;
 #pragma unroll
-            for (int qi = 0; qi < 8; ++qi) {
-                const int q = qo * 8 + qi;
-                const float4 av = *reinterpret_cast<const float4 *>(arow + 16 * q);
-                const float4 bv = breg[qi];
-                if (qo < 7) breg[qi] = *reinterpret_cast<const float4 *>(brow + 16 * (q + 8));
-                acc = mfma16(av.x, bv.x, acc);
-                acc = mfma16(av.y, bv.y, acc);
-                acc = mfma16(av.z, bv.z, acc);
-                acc = mfma16(av.w, bv.w, acc);
+        for (int np = 0; np < 4; ++np) {        // output tiles 2np, 2np+1: ring slots (2np)&3, (2np+1)&3
+            const int s0 = (2 * np) & 3, s1 = (2 * np + 1) & 3;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < ((a.dbg & 4) ? 1 : 8); ++q) {
+                acc0 = mfma16(at[q].x, bt[s0][q].x, acc0);
+                acc1 = mfma16(at[q].x, bt[s1][q].x, acc1);
+                acc0 = mfma16(at[q].y, bt[s0][q].y, acc0);
+                acc1 = mfma16(at[q].y, bt[s1][q].y, acc1);
+                acc0 = mfma16(at[q].z, bt[s0][q].z, acc0);
+                acc1 = mfma16(at[q].z, bt[s1][q].z, acc1);
+                acc0 = mfma16(at[q].w, bt[s0][q].w, acc0);
+                acc1 = mfma16(at[q].w, bt[s1][q].w, acc1);
+            }
+            if (np < 2 && !(a.dbg & 1)) {        // refill the two slots just consumed with tiles +4
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    bt[s0][q] = W1pk[((2 * np + 4) * 8 + q) * 64];
+                    bt[s1][q] = W1pk[((2 * np + 5) * 8 + q) * 64];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mypart[(4 * g + r) * PS + 32 * np + li] = acc0[r];
+                mypart[(4 * g + r) * PS + 32 * np + 16 + li] = acc1[r];
             }
         }
-        const int h = 16 * w + li;
-        const float bias = P[a.off.iqn_b1 + h];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pre = acc[r] + bias;
-            h1[(4 * g + r) * HS + h] = fmaxf(pre, 0.f);
-            if (ps.save) a.ws.pre1[(int64_t)(r0 + 4 * g + r) * H_DIM + h] = pre;
-        }
     }
-    __syncthreads();
+    // head operands: issue now, consume after two more barriers
+    const float *g2 = P + a.off.iqn_ln2_g, *be2 = P + a.off.iqn_ln2_b;
+    const float *W2 = P + a.off.iqn_w2, *b2 = P + a.off.iqn_b2;
+    const float g2a = g2[lane], g2b = g2[lane + 64], b2a = be2[lane], b2b = be2[lane + 64];
+    float w2a[16], w2b[16], b2r[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa)
+        if (aa < A) {
+            w2a[aa] = W2[aa * H_DIM + lane];
+            w2b[aa] = W2[aa * H_DIM + 64 + lane];
+            b2r[aa] = b2[aa];
+        }
+    const float b1v0 = P[a.off.iqn_b1 + (tid & 127)];
+    lds_barrier();
+    PRISM_STAMP(5);
+    // fold the 8 K-slices in fixed order, + bias, ReLU
+    for (int idx = tid; idx < 16 * H_DIM; idx += 512) {
+        const int m = idx >> 7, h = idx & 127;
+        float s = part[m * PS + h];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) s += part[(ww * 16 + m) * PS + h];
+        const float pre = s + b1v0;             // h == tid & 127 for every idx of this thread
+        h1[m * HS + h] = fmaxf(pre, 0.f);
+        if (ps.save) a.ws.pre1[(int64_t)(r0 + m) * H_DIM + h] = pre;
+    }
+    lds_barrier();
 
+    PRISM_STAMP(6);
     // ---- LayerNorm(128) + head (128 -> A): wave w owns rows 2w, 2w+1 ---------------------------
     {
-        const float *g2 = P + a.off.iqn_ln2_g, *be2 = P + a.off.iqn_ln2_b;
-        const float *W2 = P + a.off.iqn_w2, *b2 = P + a.off.iqn_b2;
-        const float g2a = g2[lane], g2b = g2[lane + 64], b2a = be2[lane], b2b = be2[lane + 64];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int m = 2 * w + rr;
@@ -318,34 +444,66 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
                 a.ws.xhat2[(int64_t)(r0 + m) * H_DIM + 64 + lane] = xh1;
                 if (lane == 0) a.ws.rstd2[r0 + m] = rstd;
             }
-            for (int aa = 0; aa < A; ++aa) {
-                const float z = wave_sum(y0 * W2[aa * H_DIM + lane] + y1 * W2[aa * H_DIM + 64 + lane]) + b2[aa];
-                if (lane == 0) ps.z_out[(int64_t)(r0 + m) * A + aa] = z;
-            }
+#pragma unroll
+            for (int aa = 0; aa < 16; ++aa)
+                if (aa < A) {
+                    const float z = wave_sum(y0 * w2a[aa] + y1 * w2b[aa]) + b2r[aa];
+                    if (lane == 0) ps.z_out[(int64_t)(r0 + m) * A + aa] = z;
+                }
         }
     }
+    PRISM_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
-// loss: one wave (64 lanes) per sample.  T, T' must divide 64.
+// loss: one workgroup (8 waves) per sample.  Wave 0 evaluates the pairwise quantile-Huber tile
+// while every wave already has the saved activations of its rows in flight; then the T
+// current-state rows are back-propagated through head + LayerNorm(128), rows strided over waves.
+// T, T' must divide 64.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void iqn_loss_kernel(IqnArgs a) {
+constexpr int LOSS_WAVES = 8;
+constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
+
+__global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
     __shared__ float s_zc[64 * 16], s_zo[64 * 16], s_zt[64 * 16];
     __shared__ float s_y[64], s_q[64], s_tau[64], s_dq[64];
+    __shared__ float s_acc[LOSS_WAVES][4 * 64 + 4];
     __shared__ int s_astar;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
     const float kap = a.huber_k;
-    const float *zon_g = a.ws.zon, *ztg_g = a.ws.ztg;
-    for (int i = lane; i < T * A; i += 64) s_zc[i] = a.ws.zcur[(int64_t)b * T * A + i];
-    for (int i = lane; i < Tn * A; i += 64) {
-        s_zo[i] = zon_g[(int64_t)b * Tn * A + i];
-        s_zt[i] = ztg_g[(int64_t)b * Tn * A + i];
+
+    // rows of this wave: t = w, w + 8, ...; start their loads now, they do not depend on the loss
+    float xa[LOSS_RPW], xb[LOSS_RPW], pa[LOSS_RPW], pb[LOSS_RPW], rs[LOSS_RPW];
+#pragma unroll
+    for (int i = 0; i < LOSS_RPW; ++i) {
+        const int t = w + LOSS_WAVES * i;
+        if (t < T) {
+            const int64_t r = (int64_t)b * T + t;
+            xa[i] = a.ws.xhat2[r * H_DIM + lane];
+            xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
+            pa[i] = a.ws.pre1[r * H_DIM + lane];
+            pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
+            rs[i] = a.ws.rstd2[r];
+        }
+    }
+    const int act = (int)a.action[b];
+    const float *P = a.params;
+    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
+    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
+    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
+    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
+    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
+
+    for (int i = tid; i < T * A; i += 64 * LOSS_WAVES) s_zc[i] = a.ws.zcur[(int64_t)b * T * A + i];
+    for (int i = tid; i < Tn * A; i += 64 * LOSS_WAVES) {
+        s_zo[i] = a.ws.zon[(int64_t)b * Tn * A + i];
+        s_zt[i] = a.ws.ztg[(int64_t)b * Tn * A + i];
     }
     // quantile samples of the current-state pass (tau_out slot 0 always holds them)
-    if (lane < T) s_tau[lane] = a.tau_out[(int64_t)lane * B + b];
+    if (tid < T) s_tau[tid] = a.tau_out[(int64_t)tid * B + b];
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133)
         int best = 0;
         float bestv = 0.f;
@@ -361,78 +519,87 @@ __global__ __launch_bounds__(64) void iqn_loss_kernel(IqnArgs a) {
         s_astar = best;
     }
     __syncthreads();
-    const int act = (int)a.action[b];
-    const float R = a.reward[b];
-    const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-    if (lane < Tn) s_y[lane] = R + s_zt[lane * A + s_astar] * dg;   // separate mul and add (iqn_model.py:145)
-    if (lane < T) s_q[lane] = s_zc[lane * A + act];
-    __syncthreads();
-    // pairwise quantile-Huber tile: pair p = j*T + t; lane keeps a fixed t because T | 64
-    float lsum = 0.f, gq = 0.f;
-    const int t_l = lane % T;
-    for (int p = lane; p < T * Tn; p += 64) {
-        const int j = p / T;
-        const float d = s_y[j] - s_q[t_l];
-        const float ad = fabsf(d);
-        const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
-        const float wgt = fabsf(s_tau[t_l] - (d < 0.f ? 1.0f : 0.0f));
-        lsum += (wgt * hub) / kap;
-        const float cl = fminf(fmaxf(d, -kap), kap);
-        gq += (wgt * cl) / kap;
-    }
-    lsum = wave_sum(lsum);
-    for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
-    const float dl = (lsum / (float)Tn) * a.dist_w;
-    const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
-    const float scale = -(wb / (float)B) * a.dist_w / (float)Tn;
-    if (lane < T) s_dq[lane] = gq * scale;
-    if (lane == 0) {
-        a.out_dl[b] = dl;
-        if (a.out_td) a.out_td[b] = dl;      // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
-        a.ws.lossw[b] = dl * wb;
+    if (w == 0) {
+        const float R = a.reward[b];
+        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + s_astar] * dg;   // separate mul and add (iqn_model.py:145)
+        if (lane < T) s_q[lane] = s_zc[lane * A + act];
+        __builtin_amdgcn_wave_barrier();
+        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
+        float lsum = 0.f, gq = 0.f;
+        const int t_l = lane % T;
+        const float q_l = s_q[t_l], tau_l = s_tau[t_l];
+        for (int p = lane; p < T * Tn; p += 64) {
+            const int j = p / T;
+            const float d = s_y[j] - q_l;
+            const float ad = fabsf(d);
+            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
+            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
+            lsum += (wgt * hub) / kap;
+            const float cl = fminf(fmaxf(d, -kap), kap);
+            gq += (wgt * cl) / kap;
+        }
+        lsum = wave_sum(lsum);
+        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
+        const float dl = (lsum / (float)Tn) * a.dist_w;
+        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+        const float scale = -(wb / (float)B) * a.dist_w / (float)Tn;
+        if (lane < T) s_dq[lane] = gq * scale;
+        if (lane == 0) {
+            a.out_dl[b] = dl;
+            if (a.out_td) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
+            a.ws.lossw[b] = dl * wb;
+        }
     }
     __syncthreads();
 
-    // head + LayerNorm(128) backward for the T current-state rows of this sample
-    const float *P = a.params;
-    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
-    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
-    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
-    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
-    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
+    // head + LayerNorm(128) backward for this wave's rows
     float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const int64_t r = (int64_t)b * T + t;
-        const float dq = s_dq[t];
-        const float xa = a.ws.xhat2[r * H_DIM + lane], xb = a.ws.xhat2[r * H_DIM + 64 + lane];
-        const float pa = a.ws.pre1[r * H_DIM + lane], pb = a.ws.pre1[r * H_DIM + 64 + lane];
-        const float rstd = a.ws.rstd2[r];
-        const float da = dq * w2a, db = dq * w2b;
-        const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
-        const float m2 = wave_sum(da * xa + db * xb) * (1.0f / H_DIM);
-        float ga = rstd * (da - m1 - xa * m2), gb = rstd * (db - m1 - xb * m2);
-        ga = pa > 0.f ? ga : 0.f;
-        gb = pb > 0.f ? gb : 0.f;
-        a.ws.dpre1[r * H_DIM + lane] = ga;
-        a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
-        const float c1 = wave_sum(ga * ua + gb * ub);
-        const float c2 = wave_sum(ga * (pa - va) + gb * (pb - vb));
-        if (lane == 0) {
-            a.ws.c1[r] = c1;
-            a.ws.c2[r] = c2;
-            a.ws.dq[r] = dq;
+#pragma unroll
+    for (int i = 0; i < LOSS_RPW; ++i) {
+        const int t = w + LOSS_WAVES * i;
+        if (t < T) {
+            const int64_t r = (int64_t)b * T + t;
+            const float dq = s_dq[t];
+            const float da = dq * w2a, db = dq * w2b;
+            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
+            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
+            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
+            ga = pa[i] > 0.f ? ga : 0.f;
+            gb = pb[i] > 0.f ? gb : 0.f;
+            a.ws.dpre1[r * H_DIM + lane] = ga;
+            a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
+            const float c1 = wave_sum(ga * ua + gb * ub);
+            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+            if (lane == 0) {
+                a.ws.c1[r] = c1;
+                a.ws.c2[r] = c2;
+                a.ws.dq[r] = dq;
+            }
+            Sa += dq * xa[i];
+            Sbb += dq * xb[i];
+            Pa += ga;
+            Pbb += gb;
+            Dsum += dq;
         }
-        Sa += dq * xa;
-        Sbb += dq * xb;
-        Pa += ga;
-        Pbb += gb;
-        Dsum += dq;
     }
-    a.ws.Sb[(int64_t)b * H_DIM + lane] = Sa;
-    a.ws.Sb[(int64_t)b * H_DIM + 64 + lane] = Sbb;
-    a.ws.Pb[(int64_t)b * H_DIM + lane] = Pa;
-    a.ws.Pb[(int64_t)b * H_DIM + 64 + lane] = Pbb;
-    if (lane == 0) a.ws.Db[b] = Dsum;
+    s_acc[w][lane] = Sa;
+    s_acc[w][64 + lane] = Sbb;
+    s_acc[w][128 + lane] = Pa;
+    s_acc[w][192 + lane] = Pbb;
+    if (lane == 0) s_acc[w][256] = Dsum;
+    __syncthreads();
+    if (tid < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][tid];
+        if (tid < 128) a.ws.Sb[(int64_t)b * H_DIM + tid] = t;
+        else a.ws.Pb[(int64_t)b * H_DIM + (tid - 128)] = t;
+    } else if (tid == 256) {
+        float t = 0.f;
+        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][256];
+        a.ws.Db[b] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -442,6 +609,12 @@ __global__ __launch_bounds__(64) void iqn_loss_kernel(IqnArgs a) {
 // ------------------------------------------------------------------------------------------
 constexpr int BWD_WAVE_LDS = 16 * CS + 16 * HS;     // floats per wave (cos tile + dpre1 tile)
 constexpr int BWD_ACC = 16 + 32 + 3;                // accumulators reduced across waves
+#ifndef BWD_PREFETCH
+#define BWD_PREFETCH 0
+#endif
+#ifndef BWD_CHUNKS
+#define BWD_CHUNKS 8
+#endif
 
 __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -461,6 +634,7 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
     float *dpl = cosl + 16 * CS;
     const float *P = a.params;
 
+    PRISM_STAMP(8);
     // per-lane constants ------------------------------------------------------------------------
     float4 wphi[4];   // B operand of phi: Wphi[n][16q + 4g + jj]
     {
@@ -485,53 +659,60 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
     for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
 
-    for (int ti = 0; ti < tiles_per_wave; ++ti) {
+    PRISM_STAMP(9);
+    // operands of one 16-row tile, fetched one tile ahead of the MFMA work (software prefetch: with a
+    // single wave per SIMD nothing else hides the L2 latency)
+    struct TileIn {
+        float4 ac[4], ad[8];     // A fragments: cos rows / dpre1 rows (row = r0 + j, k = 16q + 4g + jj)
+        float4 mu, rs, c1, c2;   // row scalars of the D-layout rows 4g..4g+3
+        float ev;
+        int bsm;
+    };
+    auto load_tile = [&](TileIn &t, int ti) {
         const int r0 = (tile_begin + ti) * 16;
-        // A fragments (row = r0 + j, k = 16q + 4g + jj)
-        float4 ac[4], ad[8];
-        {
-            const float *src = a.ws.cosb + (int64_t)(r0 + j) * K_BASIS + 4 * g;
+        const float *src = a.ws.cosb + (int64_t)(r0 + j) * K_BASIS + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ac[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-            const float *sd = a.ws.dpre1 + (int64_t)(r0 + j) * H_DIM + 4 * g;
+        for (int q = 0; q < 4; ++q) t.ac[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
+        const float *sd = a.ws.dpre1 + (int64_t)(r0 + j) * H_DIM + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
-        }
+        for (int q = 0; q < 8; ++q) t.ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
+        const int rb = r0 + 4 * g;
+        t.bsm = rb / T;
+        t.mu = *reinterpret_cast<const float4 *>(a.ws.mu1 + rb);
+        t.rs = *reinterpret_cast<const float4 *>(a.ws.rstd1 + rb);
+        t.c1 = *reinterpret_cast<const float4 *>(a.ws.c1 + rb);
+        t.c2 = *reinterpret_cast<const float4 *>(a.ws.c2 + rb);
+        t.ev = a.ws.e_cur[(int64_t)t.bsm * E_DIM + n];
+    };
+    auto process_tile = [&](const TileIn &t, int ti) {
+        const int r0 = (tile_begin + ti) * 16;
         // stage both tiles in LDS for the k-major reads of the weight-gradient products
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&cosl[j * CS + 16 * q + 4 * g]) = ac[q];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&cosl[j * CS + 16 * q + 4 * g]) = t.ac[q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
-
-        // row scalars for the D-layout rows 4g..4g+3
-        const int rb = r0 + 4 * g;
-        const int bsm = rb / T;
-        const float4 mu = *reinterpret_cast<const float4 *>(a.ws.mu1 + rb);
-        const float4 rs = *reinterpret_cast<const float4 *>(a.ws.rstd1 + rb);
-        const float4 c1 = *reinterpret_cast<const float4 *>(a.ws.c1 + rb);
-        const float4 c2 = *reinterpret_cast<const float4 *>(a.ws.c2 + rb);
-        const float ev = a.ws.e_cur[(int64_t)bsm * E_DIM + n];
-
-        // phi columns and dX columns, two independent MFMA chains interleaved
-        f32x4 aphi = {0.f, 0.f, 0.f, 0.f}, adx = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = t.ad[q];
+        const int bsm = t.bsm;
+        const float ev = t.ev;
+        // phi columns and dX columns: three independent MFMA chains interleaved
+        f32x4 aphi = {0.f, 0.f, 0.f, 0.f}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            aphi = mfma16(ac[q].x, wphi[q].x, aphi);
-            adx = mfma16(ad[2 * q].x, w1f[8 * q + 0], adx);
-            aphi = mfma16(ac[q].y, wphi[q].y, aphi);
-            adx = mfma16(ad[2 * q].y, w1f[8 * q + 1], adx);
-            aphi = mfma16(ac[q].z, wphi[q].z, aphi);
-            adx = mfma16(ad[2 * q].z, w1f[8 * q + 2], adx);
-            aphi = mfma16(ac[q].w, wphi[q].w, aphi);
-            adx = mfma16(ad[2 * q].w, w1f[8 * q + 3], adx);
-            adx = mfma16(ad[2 * q + 1].x, w1f[8 * q + 4], adx);
-            adx = mfma16(ad[2 * q + 1].y, w1f[8 * q + 5], adx);
-            adx = mfma16(ad[2 * q + 1].z, w1f[8 * q + 6], adx);
-            adx = mfma16(ad[2 * q + 1].w, w1f[8 * q + 7], adx);
+            aphi = mfma16(t.ac[q].x, wphi[q].x, aphi);
+            adx = mfma16(t.ad[2 * q].x, w1f[8 * q + 0], adx);
+            adx2 = mfma16(t.ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
+            aphi = mfma16(t.ac[q].y, wphi[q].y, aphi);
+            adx = mfma16(t.ad[2 * q].y, w1f[8 * q + 1], adx);
+            adx2 = mfma16(t.ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
+            aphi = mfma16(t.ac[q].z, wphi[q].z, aphi);
+            adx = mfma16(t.ad[2 * q].z, w1f[8 * q + 2], adx);
+            adx2 = mfma16(t.ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
+            aphi = mfma16(t.ac[q].w, wphi[q].w, aphi);
+            adx = mfma16(t.ad[2 * q].w, w1f[8 * q + 3], adx);
+            adx2 = mfma16(t.ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
         }
         // elementwise backward on the 4 rows this lane holds (column n)
-        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-        const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
+        const float muv[4] = {t.mu.x, t.mu.y, t.mu.z, t.mu.w}, rsv[4] = {t.rs.x, t.rs.y, t.rs.z, t.rs.w};
+        const float c1v[4] = {t.c1.x, t.c1.y, t.c1.z, t.c1.w}, c2v[4] = {t.c2.x, t.c2.y, t.c2.z, t.c2.w};
         float xv[4], dpp[4];
         float dep = 0.f;
 #pragma unroll
@@ -540,7 +721,7 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
             const float h0 = phi * ev;
             const float xhat = (h0 - muv[r]) * rsv[r];
             xv[r] = xhat * g1 + be1;                  // LN output (B operand of dW1)
-            const float dX = adx[r];
+            const float dX = adx[r] + adx2[r];
             s_dg += dX * xhat;
             s_db += dX;
             const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
@@ -564,22 +745,45 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
                 de_acc = 0.f;
             }
         }
-        // dWphi[n-slice][64] += dphi^T (16 cols x 16 rows) . cos (16 rows x 64): A = dpp (D layout == A^T layout)
+        // dWphi[n-slice][64] += dphi^T (16 cols x 16 rows) . cos (16 rows x 64)   (A = dpp: D layout == A^T layout)
+        // dW1[128][n-slice]  += dpre1^T (128 x 16 rows) . X (16 rows x 16 cols)    (B = xv)
+        // k-step outer, accumulator inner: consecutive MFMAs never touch the same accumulator
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accWphi[kt] = mfma16(dpp[r], cosl[(4 * g + r) * CS + 16 * kt + j], accWphi[kt]);
+            for (int kt = 0; kt < 4; ++kt)
+                accWphi[kt] = mfma16(dpp[r], cosl[(4 * g + r) * CS + 16 * kt + j], accWphi[kt]);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
         }
-        // dW1[128][n-slice] += dpre1^T (128 x 16 rows) . X (16 rows x 16 cols): B = xv
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
+    };
+#if BWD_PREFETCH
+    {
+        TileIn tA, tB;
+        if (tiles_per_wave > 0) load_tile(tA, 0);
+        for (int ti = 0; ti < tiles_per_wave; ti += 2) {
+            const bool has_b = ti + 1 < tiles_per_wave;
+            if (has_b) load_tile(tB, ti + 1);
+            process_tile(tA, ti);
+            if (has_b) {
+                if (ti + 2 < tiles_per_wave) load_tile(tA, ti + 2);
+                process_tile(tB, ti + 1);
+            }
         }
     }
+#else
+    for (int ti = 0; ti < tiles_per_wave; ++ti) {   // two workgroups per CU hide the load latency instead
+        TileIn tA;
+        load_tile(tA, ti);
+        process_tile(tA, ti);
+    }
+#endif
 
+    PRISM_STAMP(10);
     // ---- reduce the four waves in fixed order and write this workgroup's slab part -------------
     __syncthreads();
+    PRISM_STAMP(11);
     float *red = smem;    // [4 waves][BWD_ACC][64]
     {
         float *mine = red + (w * BWD_ACC) * 64 + lane;
@@ -624,108 +828,124 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
             else slab[E_DIM * K_BASIS + nn] = v;                              // d phi_b
         }
     }
+    PRISM_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------------------
-// small: blocks [0, 16*CONV_CHUNKS): conv backward partials; last block: b1, LN2, W2, b2.
+// Block routines of the post kernel (step_kernels.h): conv-backward partials and the small tensors.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void iqn_small_kernel(IqnArgs a) {
-    __shared__ float s_obs[1024];
-    __shared__ float s_dc[64];
-    __shared__ float s_red[1024 + 64];
-    const int tid = threadIdx.x, B = a.B, C = a.C, A = a.A;
-    const int n_conv_blocks = 16 * CONV_CHUNKS;
-    if ((int)blockIdx.x < n_conv_blocks) {
-        const int c = blockIdx.x / CONV_CHUNKS, ch = blockIdx.x % CONV_CHUNKS;
-        const int per = (B + CONV_CHUNKS - 1) / CONV_CHUNKS;
-        const int b0 = ch * per, b1 = min(B, b0 + per);
-        const int nk = 9 * C;                 // (ci, dy, dx)
-        const bool active = tid < nk * 8;     // thread = (k, y)
-        const int k = tid >> 3, y = tid & 7;
-        const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
-        float acc = 0.f, bacc = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            __syncthreads();
-            for (int i = tid; i < 100 * C; i += 1024) s_obs[i] = a.obs[(int64_t)b * 100 * C + i];
-            if (tid < 64) {
-                const int64_t o = (int64_t)b * E_DIM + c * 64 + tid;
-                const float d = a.propagate_grad ? a.ws.de_iqn[o] : 0.f;
-                s_dc[tid] = a.ws.e_cur[o] > 0.f ? d : 0.f;
-            }
-            __syncthreads();
-            if (active) {
-#pragma unroll
-                for (int x = 0; x < 8; ++x) acc = fmaf(s_dc[y * 8 + x], s_obs[((y + dy) * 10 + (x + dx)) * C + ci], acc);
-            }
-            if (tid < 64) bacc += s_dc[tid];
-        }
-        __syncthreads();
-        s_red[tid] = active ? acc : 0.f;
-        if (tid < 64) s_red[1024 + tid] = bacc;
-        __syncthreads();
-        float *out = a.ws.convpart + (int64_t)(c * CONV_CHUNKS + ch) * 96;
-        if (tid < nk) {
-            float s = 0.f;
-#pragma unroll
-            for (int yy = 0; yy < 8; ++yy) s += s_red[tid * 8 + yy];
-            out[tid] = s;
-        }
-        if (tid == 0) {
-            float s = 0.f;
-            for (int i = 0; i < 64; ++i) s += s_red[1024 + i];
-            out[95] = s;
-        }
-        return;
+constexpr int CONV_SPB = 4;              // samples per conv-backward block
+constexpr int CONV_ROW = 16 * 90 + 16;   // floats per partial row: 16 * 9C weights (C <= 10) + 16 biases
+constexpr int SMALL_MAX_B = 4096;
+
+// d conv_w / d conv_b partial sums over samples [cb*CONV_SPB, ...) for all 16 output channels.
+// s_obs: [CONV_SPB][1000] floats, s_dc: [CONV_SPB][16*65] floats of LDS.  1024 threads.
+__device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *s_obs, float *s_dc) {
+    const int tid = threadIdx.x, B = a.B, C = a.C;
+    const int b0 = cb * CONV_SPB, ns = min(CONV_SPB, B - b0);
+#pragma unroll 2
+    for (int i = tid; i < ns * 100 * C; i += 1024) {
+        const int s = i / (100 * C), o = i - s * 100 * C;
+        s_obs[s * 1000 + o] = a.obs[(int64_t)(b0 + s) * 100 * C + o];
     }
-    // ---- small tensors: S[a][h] = sum_{b: act=a} Sb[b][h]; D[a]; db1[h] = sum_b Pb[b][h] -------
-    __shared__ float s_S[16 * H_DIM];
-    __shared__ float s_D[16];
-    const int h = tid & 127, part = tid >> 7;       // 8 parts over the batch
-    const int per = (B + 7) / 8, b0 = part * per, b1 = min(B, b0 + per);
-    float *gr = a.grads;
-    const float *P = a.params;
-    float sq = 0.f;
-    for (int aa = 0; aa < A; ++aa) {
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b)
-            if ((int)a.action[b] == aa) s += a.ws.Sb[(int64_t)b * H_DIM + h];
-        __syncthreads();
-        s_red[tid] = s;
-        __syncthreads();
-        if (part == 0) {
-            float t = 0.f;
-            for (int p = 0; p < 8; ++p) t += s_red[p * 128 + h];
-            s_S[aa * H_DIM + h] = t;
-        }
-    }
-    {
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += a.ws.Pb[(int64_t)b * H_DIM + h];
-        __syncthreads();
-        s_red[tid] = s;
-        __syncthreads();
-        if (part == 0) {
-            float t = 0.f;
-            for (int p = 0; p < 8; ++p) t += s_red[p * 128 + h];
-            gr[a.off.iqn_b1 + h] = t;
-            sq += t * t;
-        }
-    }
-    if (tid < A) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b)
-            if ((int)a.action[b] == tid) s += a.ws.Db[b];
-        s_D[tid] = s;
-        gr[a.off.iqn_b2 + tid] = s;
-        sq += s * s;
+#pragma unroll 4
+    for (int i = tid; i < ns * E_DIM; i += 1024) {
+        const int s = i >> 10, n = i & 1023;
+        const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
+        const float d = a.propagate_grad ? a.ws.de_iqn[o] : 0.f;
+        s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
+    const int nk = 9 * C;
+    float *out = a.ws.convpart + (int64_t)cb * CONV_ROW;
+    for (int o = tid; o < 16 * nk; o += 1024) {
+        const int c = o / nk, k = o - c * nk;
+        const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            const float *dc = &s_dc[s * (16 * 65) + c * 65];
+            const float *ob = &s_obs[s * 1000 + (dy * 10 + dx) * C + ci];
+#pragma unroll
+            for (int y = 0; y < 8; ++y)
+#pragma unroll
+                for (int x = 0; x < 8; ++x) acc = fmaf(dc[y * 8 + x], ob[(y * 10 + x) * C], acc);
+        }
+        out[o] = acc;
+    }
+    if (tid < 16) {
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s)
+            for (int i = 0; i < 64; ++i) acc += s_dc[s * (16 * 65) + tid * 65 + i];
+        out[16 * nk + tid] = acc;
+    }
+}
+
+// b1, LN2 affine, W2, b2 gradients for the 64 hidden units [slice*64, slice*64+64).
+//   S[a][h] = sum_{b: act=a} Sb[b][h];  D[a] = sum_{b: act=a} Db[b];  db1[h] = sum_b Pb[b][h]
+//   dW2[a][h] = g2[h] S[a][h] + beta2[h] D[a];  dg2[h] = sum_a W2[a][h] S[a][h];  dbeta2[h] = sum_a W2[a][h] D[a]
+// 1024 threads = 64 units x 16 batch parts.  Slice 0 also writes db2 and the total loss.
+__device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq) {
+    __shared__ float s_part[16][64];
+    __shared__ float s_S[16][64];
+    __shared__ float s_D[16];
+    __shared__ float s_lw[16];
+    const int tid = threadIdx.x, B = a.B, A = a.A;
+    const int hl = tid & 63, part = tid >> 6, h = slice * 64 + hl;
+    float sA[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
+    float pb = 0.f;
+#pragma unroll 4
+    for (int b = part; b < B; b += 16) {
+        const float v = a.ws.Sb[(int64_t)b * H_DIM + h];
+        pb += a.ws.Pb[(int64_t)b * H_DIM + h];
+        const int ab = (int)a.action[b];
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
+    }
+    {   // D[a]: one wave per action (wave index == part)
+        float s = 0.f, lw = 0.f;
+        if (part < A)
+            for (int b = hl; b < B; b += 64) s += ((int)a.action[b] == part) ? a.ws.Db[b] : 0.f;
+        if (slice == 0)
+            for (int b = tid; b < B; b += 1024) lw += a.ws.lossw[b];
+        s = wave_sum(s);
+        lw = wave_sum(lw);
+        if (hl == 0) {
+            s_D[part] = s;
+            s_lw[part] = lw;
+        }
+    }
+    float *gr = a.grads;
+    const float *P = a.params;
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) {
+        if (aa < A) {
+            __syncthreads();
+            s_part[part][hl] = sA[aa];
+            __syncthreads();
+            if (part == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+                s_S[aa][hl] = t;
+            }
+        }
+    }
+    __syncthreads();
+    s_part[part][hl] = pb;
+    __syncthreads();
     if (part == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+        gr[a.off.iqn_b1 + h] = t;
+        sq += t * t;
         const float g2 = P[a.off.iqn_ln2_g + h], be2 = P[a.off.iqn_ln2_b + h];
         float dg = 0.f, db = 0.f;
         for (int aa = 0; aa < A; ++aa) {
             const float w2 = P[a.off.iqn_w2 + aa * H_DIM + h];
-            const float S = s_S[aa * H_DIM + h], D = s_D[aa];
+            const float S = s_S[aa][hl], D = s_D[aa];
             const float dw = g2 * S + be2 * D;
             gr[a.off.iqn_w2 + aa * H_DIM + h] = dw;
             sq += dw * dw;
@@ -736,70 +956,20 @@ __global__ __launch_bounds__(1024) void iqn_small_kernel(IqnArgs a) {
         gr[a.off.iqn_ln2_b + h] = db;
         sq += dg * dg + db * db;
     }
-    // total loss (agent.py:58-64) and this block's sum of squares
-    __syncthreads();
-    s_red[tid] = sq;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int i = 0; i < 1024; ++i) t += s_red[i];
-        a.ws.normpart[NORM_SLOTS - 1] = t;
+    if (slice == 0 && tid < A) {
+        const float D = s_D[tid];
+        gr[a.off.iqn_b2 + tid] = D;
+        sq += D * D;
+    }
+    if (slice == 0 && tid == 0) {
         float l = 0.f;
-        for (int b = 0; b < B; ++b) l += a.ws.lossw[b];
-        l = l / (float)B;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) l += s_lw[p];
+        l = l / (float)B;       // mean_b(dl_b * w_b)  (agent.py:58-64)
         a.out_scalars[0] = l;
         a.out_scalars[1] = l;
         a.out_scalars[2] = 0.f;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// reduce: slabs -> grads[phi_w .. w1], conv partials -> grads[conv]; per-block sum of squares.
-// grid = REDUCE_BLOCKS, 256 threads, grid-stride over SLAB/4 float4 + conv.
-// ------------------------------------------------------------------------------------------
-constexpr int REDUCE_BLOCKS = 195;   // SLAB/4 = 49920 float4 = 195 * 256
-
-__global__ __launch_bounds__(256) void iqn_reduce_kernel(IqnArgs a) {
-    __shared__ float s_red[256];
-    const int tid = threadIdx.x;
-    float sq = 0.f;
-    const int nvec = SLAB / 4;
-    float *gbase = a.grads + a.off.phi_w;
-    for (int i = blockIdx.x * 256 + tid; i < nvec; i += gridDim.x * 256) {
-        float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
-        for (int c = 1; c < a.n_chunks; ++c) {
-            const float4 v = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * SLAB)[i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        gbase[4 * i + 0] = s.x;
-        gbase[4 * i + 1] = s.y;
-        gbase[4 * i + 2] = s.z;
-        gbase[4 * i + 3] = s.w;
-        sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
-    }
-    if (blockIdx.x == 0) {
-        const int nk = 9 * a.C;
-        for (int i = tid; i < 16 * nk + 16; i += 256) {
-            float s = 0.f;
-            if (i < 16 * nk) {
-                const int c = i / nk, k = i % nk;
-                for (int ch = 0; ch < CONV_CHUNKS; ++ch) s += a.ws.convpart[(int64_t)(c * CONV_CHUNKS + ch) * 96 + k];
-                a.grads[a.off.conv_w + i] = s;
-            } else {
-                const int c = i - 16 * nk;
-                for (int ch = 0; ch < CONV_CHUNKS; ++ch) s += a.ws.convpart[(int64_t)(c * CONV_CHUNKS + ch) * 96 + 95];
-                a.grads[a.off.conv_b + c] = s;
-            }
-            sq += s * s;
-        }
-    }
-    s_red[tid] = sq;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) s_red[tid] += s_red[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) a.ws.normpart[blockIdx.x] = s_red[0];
 }
 
 }  // namespace prism

@@ -1,10 +1,12 @@
-// TD update entry points: get_losses + backward (prism_learner_fwd_bwd) and
-// clip_grad_norm_ + Adam (prism_learner_clip_adam).  Reference:
-//   /root/reference/prism/agents/models/composite_model.py:94-144, prism/agents/agent.py:53-79.
+// TD update entry points: get_losses + backward (prism_learner_fwd_bwd), clip_grad_norm_ + Adam
+// (prism_learner_clip_adam), and the fused step front/back (prism_step_front / prism_step_back).
+// Reference: /root/reference/prism/agents/models/composite_model.py:94-144,
+// prism/agents/agent.py:53-79, prism/learner.py:95-125.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
-#include "iqn_kernels.h"
+#include "step_kernels.h"
 
 namespace prism {
 
@@ -16,7 +18,7 @@ struct AdamArgs {
     int64_t n;
     int64_t *step;
     const float *normpart;
-    int n_front, use_tail;
+    int n_slots;
     double lr, b1, b2, eps;
     float max_norm, grad_scale;
     float *out_scalars;
@@ -42,14 +44,15 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict
     if (threadIdx.x == 0) normpart[blockIdx.x] = s_red[0];
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) {
+// One 256-thread block of the clip + Adam update (block `blk` of `nblk`).
+__device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int nblk) {
     __shared__ float s_red[256];
-    __shared__ float s_coef;
+    __shared__ float s_c[4];     // clip coef, -step_size, sqrt(bias_correction2)
     const int tid = threadIdx.x;
     // every block folds the same partials in the same order -> identical norm everywhere
     float s = 0.f;
-    for (int i = tid; i < a.n_front; i += 256) s += a.normpart[i];
-    if (tid == 0 && a.use_tail) s += a.normpart[NORM_SLOTS - 1];
+#pragma unroll 4
+    for (int i = tid; i < a.n_slots; i += 256) s += a.normpart[i];
     s_red[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -60,40 +63,74 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) {
         const float total = sqrtf(s_red[0]);
         float coef = a.max_norm / (total + 1e-6f);   // torch.nn.utils.clip_grad_norm_
         coef = fminf(coef, 1.0f);
-        s_coef = coef;
-        if (blockIdx.x == 0) {
+        // torch.optim.Adam (_single_tensor_adam): bias corrections in float64 from the step count
+        const double t = (double)(a.step[0] + 1);
+        const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
+        s_c[0] = coef;
+        s_c[1] = (float)(-(a.lr / bc1));
+        s_c[2] = (float)sqrt(bc2);
+        if (blk == 0) {
             a.out_scalars[3] = total;
             a.out_scalars[5] = coef;
         }
     }
     __syncthreads();
-    const float coef = s_coef;
-    // torch.optim.Adam (_single_tensor_adam): bias corrections in float64 from the step count
-    const double t = (double)(a.step[0] + 1);
-    const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
-    const float neg_step = (float)(-(a.lr / bc1));
-    const float bc2s = (float)sqrt(bc2);
+    const float coef = s_c[0], neg_step = s_c[1], bc2s = s_c[2];
     const float w1 = (float)(1.0 - a.b1), b2f = (float)a.b2, w2 = (float)(1.0 - a.b2), epsf = (float)a.eps;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < a.n; i += (int64_t)gridDim.x * 256) {
-        const float g = (a.g[i] * a.grad_scale) * coef;
-        float m = a.m[i], v = a.v[i];
+    const float gs = a.grad_scale;
+    auto upd = [&](float g_, float &p, float &m, float &v) {
+        const float g = (g_ * gs) * coef;
         m = fmaf(w1, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
         v = v * b2f + (w2 * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
         const float denom = sqrtf(v) / bc2s + epsf;
-        a.p[i] = a.p[i] + (neg_step * m) / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
+        p = p + (neg_step * m) / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
+    };
+    const int64_t nvec = a.n >> 2;
+    for (int64_t i = (int64_t)blk * 256 + tid; i < nvec; i += (int64_t)nblk * 256) {
+        const float4 g = reinterpret_cast<const float4 *>(a.g)[i];
+        float4 p = reinterpret_cast<float4 *>(a.p)[i];
+        float4 m = reinterpret_cast<float4 *>(a.m)[i];
+        float4 v = reinterpret_cast<float4 *>(a.v)[i];
+        upd(g.x, p.x, m.x, v.x);
+        upd(g.y, p.y, m.y, v.y);
+        upd(g.z, p.z, m.z, v.z);
+        upd(g.w, p.w, m.w, v.w);
+        reinterpret_cast<float4 *>(a.p)[i] = p;
+        reinterpret_cast<float4 *>(a.m)[i] = m;
+        reinterpret_cast<float4 *>(a.v)[i] = v;
+    }
+    if (blk == 0 && tid < (int)(a.n & 3)) {
+        const int64_t i = (nvec << 2) + tid;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        upd(a.g[i], p, m, v);
+        a.p[i] = p;
         a.m[i] = m;
         a.v[i] = v;
     }
-    // the block that finishes last advances the step counter (all blocks have read it by then)
+    // the block that finishes last advances the step counter (every block has read it by then)
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
         const unsigned int done = atomicAdd(a.ticket, 1u);
-        if (done == gridDim.x - 1) {
+        if (done == (unsigned)(nblk - 1)) {
             a.step[0] = a.step[0] + 1;
             *a.ticket = 0u;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) { clip_adam_block(a, blockIdx.x, gridDim.x); }
+
+// back: block 0 = priority writeback (+ RNG counters); blocks [1, gridDim) = clip + Adam.
+__global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay_desc rp, BackArgs k) {
+    if (blockIdx.x == 0) {
+        if (k.use_per) per_update_block(rp, k.index, k.priority, k.n, k.alpha, k.eps, k.take_abs);
+        if (k.rng && threadIdx.x == 0) {
+            k.rng[0] += k.inc_per;
+            k.rng[1] += k.inc_tau;
+        }
+        return;
+    }
+    clip_adam_block(a, blockIdx.x - 1, gridDim.x - 1);
 }
 
 // ---- workspace carving -----------------------------------------------------------------------
@@ -115,21 +152,24 @@ static int iqn_supported(const prism_model_dims *d, int32_t B) {
         !d->use_layer_norm)
         return PRISM_ERR_UNSUPPORTED;
     if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
-    if (B < 1 || (B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
+    if (B < 1 || B > SMALL_MAX_B || (B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
     if (d->n_actions < 1 || d->n_actions > 16 || d->in_channels < 1 || d->in_channels > 10) return PRISM_ERR_UNSUPPORTED;
     return PRISM_OK;
 }
 
-static constexpr int N_CHUNKS = 4;
+static constexpr int N_CHUNKS = BWD_CHUNKS;
 
 static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws, float **tau_buf, float **dl_buf) {
     Carver c(base);
     const size_t R = (size_t)B * d->n_tau, Rn = (size_t)B * d->n_tau_next, A = d->n_actions;
     const size_t maxT = d->n_tau > d->n_tau_next ? d->n_tau : d->n_tau_next;
     IqnWs w;
+    w.ticket = (unsigned int *)c.f(4);     // first 16 bytes: the self-resetting tickets (zeroed once by the caller)
     w.e_cur = c.f((size_t)B * E_DIM);
     w.e_next = c.f((size_t)B * E_DIM);
     w.uv = c.f(2 * H_DIM);
+    w.wpk[0] = c.f(PACK_FLOATS);
+    w.wpk[1] = c.f(PACK_FLOATS);
     w.cosb = c.f(R * K_BASIS);
     w.mu1 = c.f(R);
     w.rstd1 = c.f(R);
@@ -149,9 +189,8 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.lossw = c.f(B);
     w.de_iqn = c.f((size_t)B * E_DIM);
     w.slabs = c.f((size_t)N_CHUNKS * SLAB);
-    w.convpart = c.f((size_t)16 * CONV_CHUNKS * 96);
+    w.convpart = c.f((size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW);
     w.normpart = c.f(NORM_SLOTS);
-    w.ticket = (unsigned int *)c.f(4);
     float *tb = c.f(3 * maxT * B);
     float *db = c.f(B);
     if (ws) *ws = w;
@@ -159,6 +198,8 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     if (dl_buf) *dl_buf = db;
     return c.off;
 }
+
+static int post_blocks(int B) { return POST_SLAB_BLOCKS + (B + CONV_SPB - 1) / CONV_SPB + POST_SMALL_BLOCKS; }
 
 }  // namespace prism
 
@@ -186,21 +227,18 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(ld->workspace && ld->workspace_bytes >= prism_learner_workspace_bytes(&ld->dims, ld->batch),
                     "workspace too small");
     PRISM_CHECK_ARG(((uintptr_t)ld->workspace & 15) == 0, "workspace must be 16-byte aligned");
-    PRISM_CHECK_ARG(ld->off.n_params > 0, "n_params");
-    return PRISM_OK;
-}
-
-extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream_) {
-    int rc = check_learner(ld);
-    if (rc) return rc;
+    PRISM_CHECK_ARG((((uintptr_t)ld->params | (uintptr_t)ld->grads | (uintptr_t)ld->adam_m | (uintptr_t)ld->adam_v) & 15) == 0,
+                    "parameter / gradient / Adam buffers must be 16-byte aligned");
+    PRISM_CHECK_ARG(ld->off.n_params > 0 && (ld->off.phi_w & 3) == 0, "n_params / phi_w offset alignment");
     PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
                     "null batch arrays");
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
-    hipStream_t stream = (hipStream_t)stream_;
+    return PRISM_OK;
+}
+
+static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     const prism_model_dims &d = ld->dims;
     const int B = ld->batch;
-
-    IqnArgs a;
     memset(&a, 0, sizeof(a));
     float *tau_buf = nullptr, *dl_buf = nullptr;
     carve_iqn(&d, B, ld->workspace, &a.ws, &tau_buf, &dl_buf);
@@ -215,6 +253,9 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     a.propagate_grad = d.propagate_grad;
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;
+    { const char *e = getenv("PRISM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.stamps = (unsigned long long *)ld->dbg_stamps;
+    if (!a.stamps) a.dbg &= ~8;
     a.off = ld->off;
     a.params = ld->params;
     a.target_params = ld->target_params;
@@ -227,90 +268,32 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     a.action = ld->action;
     a.seed = ld->seed;
     a.offset = ld->offset;
+    a.rng = ld->rng_counters;
     a.tau_out = ld->tau_out ? ld->tau_out : tau_buf;
     a.maxT = d.n_tau > d.n_tau_next ? d.n_tau : d.n_tau_next;
     a.out_dl = ld->out_dist_loss ? ld->out_dist_loss : dl_buf;
     a.out_td = ld->out_td;
     a.out_scalars = ld->out_scalars;
     a.grads = ld->grads;
-
     // passes, in the reference's tau draw order (iqn_model.py:104,112-126)
     int np = 0;
-    a.pass[np++] = IqnPass{ld->params, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau, B * d.n_tau / 16, 1, 0};
+    const float *pk0 = a.ws.wpk[0], *pk1 = a.ws.wpk[1];
+    a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
+                           B * d.n_tau / 16, 1, 0};
     if (!d.has_target || d.double_q) {
-        a.pass[np++] = IqnPass{ld->params, a.ws.e_next, ld->tau_next_online, a.ws.zon, d.n_tau_next,
-                               B * d.n_tau_next / 16, 0, 1};
+        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_online, a.ws.zon,
+                               d.n_tau_next, B * d.n_tau_next / 16, 0, 1};
     }
     if (d.has_target) {
-        a.pass[np++] = IqnPass{ld->target_params, a.ws.e_next, ld->tau_next_target, a.ws.ztg, d.n_tau_next,
-                               B * d.n_tau_next / 16, 0, 2};
+        a.pass[np++] = IqnPass{ld->target_params, pk1, pk1 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_target,
+                               a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2};
     }
     a.n_pass = np;
     if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
     else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
-    int total_tiles = 0;
-    for (int i = 0; i < np; ++i) total_tiles += a.pass[i].n_tiles;
-
-    static bool attr_set = false;
-    const size_t fwd_lds = TILE_FWD_LDS_FLOATS * sizeof(float);
-    const size_t bwd_lds = (size_t)(4 * BWD_ACC * 64 > 4 * BWD_WAVE_LDS ? 4 * BWD_ACC * 64 : 4 * BWD_WAVE_LDS) *
-                           sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)iqn_tile_fwd_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(tile_fwd, %zu): %s", fwd_lds, hipGetErrorString(e));
-            return PRISM_ERR_HIP;
-        }
-        attr_set = true;
-    }
-
-    {
-        ProfileScope ps_(K_EMBED, stream);
-        hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4), dim3(256), 0, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    {
-        ProfileScope ps_(K_TILE_FWD, stream);
-        hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    {
-        ProfileScope ps_(K_LOSS, stream);
-        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64), 0, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    {
-        ProfileScope ps_(K_BWD, stream);
-        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    {
-        ProfileScope ps_(K_SMALL, stream);
-        hipLaunchKernelGGL(iqn_small_kernel, dim3(16 * CONV_CHUNKS + 1), dim3(1024), 0, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    {
-        ProfileScope ps_(K_REDUCE, stream);
-        hipLaunchKernelGGL(iqn_reduce_kernel, dim3(REDUCE_BLOCKS), dim3(256), 0, stream, a);
-        PRISM_CHECK_LAUNCH();
-    }
-    if (ld->dbg_z) {
-        const size_t R = (size_t)B * d.n_tau, Rn = (size_t)B * d.n_tau_next, A = d.n_actions;
-        hipMemcpyAsync(ld->dbg_z, a.ws.zcur, R * A * 4, hipMemcpyDeviceToDevice, stream);
-        hipMemcpyAsync(ld->dbg_z + R * A, a.ws.ztg, Rn * A * 4, hipMemcpyDeviceToDevice, stream);
-    }
-    return PRISM_OK;
 }
 
-extern "C" int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream_) {
-    int rc = check_learner(ld);
-    if (rc) return rc;
-    PRISM_CHECK_ARG(ld->out_scalars, "null out_scalars");
-    hipStream_t stream = (hipStream_t)stream_;
-    IqnWs ws;
-    carve_iqn(&ld->dims, ld->batch, ld->workspace, &ws, nullptr, nullptr);
-    AdamArgs a;
+static void fill_adam_args(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a) {
     a.p = ld->params;
     a.g = ld->grads;
     a.m = ld->adam_m;
@@ -326,24 +309,178 @@ extern "C" int prism_learner_clip_adam(const prism_learner_desc *ld, prism_strea
     a.grad_scale = ld->hyper.grad_scale;
     a.out_scalars = ld->out_scalars;
     a.ticket = ws.ticket;
+}
+
+static int adam_blocks(int64_t n) {
+    int blocks = (int)(((n >> 2) + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = ld->batch;
+    IqnArgs a;
+    fill_iqn_args(ld, a);
+    int total_tiles = 0;
+    for (int i = 0; i < a.n_pass; ++i) total_tiles += a.pass[i].n_tiles;
+
+    static bool attr_set = false;
+    const size_t fwd_lds = TILE_FWD_LDS_FLOATS * sizeof(float);
+    const size_t bwd_lds = (size_t)(4 * BWD_ACC * 64 > 4 * BWD_WAVE_LDS ? 4 * BWD_ACC * 64 : 4 * BWD_WAVE_LDS) *
+                           sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)iqn_tile_fwd_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(tile_fwd, %zu): %s", fwd_lds, hipGetErrorString(e));
+            return PRISM_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    if (!ld->embed_done) {
+        ProfileScope ps_(K_EMBED, stream);
+        hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4 + PACK_BLOCKS * (1 + (ld->dims.has_target ? 1 : 0))), dim3(256), 0,
+                           stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_TILE_FWD, stream);
+        hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_LOSS, stream);
+        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_BWD, stream);
+        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    {
+        ProfileScope ps_(K_POST, stream);
+        hipLaunchKernelGGL(iqn_post_kernel, dim3(post_blocks(B)), dim3(1024), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    if (ld->dbg_z) {
+        const size_t R = (size_t)B * ld->dims.n_tau, Rn = (size_t)B * ld->dims.n_tau_next, A = ld->dims.n_actions;
+        (void)hipMemcpyAsync(ld->dbg_z, a.ws.zcur, R * A * 4, hipMemcpyDeviceToDevice, stream);
+        (void)hipMemcpyAsync(ld->dbg_z + R * A, a.ws.ztg, Rn * A * 4, hipMemcpyDeviceToDevice, stream);
+    }
+    return PRISM_OK;
+}
+
+// grid-norm partial slots valid for the Adam kernels: either what post left, or a fresh pass
+static int prepare_norm(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a, hipStream_t stream) {
     if (ld->hyper.grad_scale == 1.0f) {
-        // single replica: reuse the sum-of-squares partials the backward kernels left behind
-        a.n_front = REDUCE_BLOCKS;
-        a.use_tail = 1;
+        a.n_slots = post_blocks(ld->batch);   // single replica: reuse the partials of the post kernel
     } else {
         // data parallel: the gradient was all-reduced after the backward; recompute the partials
         const int nb = 256;
         hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nb), dim3(256), 0, stream, ld->grads, a.n, a.grad_scale,
                            ws.normpart);
         PRISM_CHECK_LAUNCH();
-        a.n_front = nb;
-        a.use_tail = 0;
+        a.n_slots = nb;
     }
-    int blocks = (int)((a.n + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    return PRISM_OK;
+}
+
+extern "C" int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    IqnWs ws;
+    carve_iqn(&ld->dims, ld->batch, ld->workspace, &ws, nullptr, nullptr);
+    AdamArgs a;
+    fill_adam_args(ld, ws, a);
+    rc = prepare_norm(ld, ws, a, stream);
+    if (rc) return rc;
     {
         ProfileScope ps_(K_CLIP_ADAM, stream);
-        hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(clip_adam_kernel, dim3(adam_blocks(a.n)), dim3(256), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    return PRISM_OK;
+}
+
+static int check_replay_for_step(const prism_learner_desc *ld, const prism_replay_desc *rp) {
+    PRISM_CHECK_ARG(rp != nullptr, "null replay descriptor");
+    PRISM_CHECK_ARG(rp->obs_elems == 100 * ld->dims.in_channels && (rp->obs_elems & 3) == 0,
+                    "replay obs_elems must equal 10*10*C");
+    PRISM_CHECK_ARG(rp->n_step >= 1 && rp->n_step <= PRISM_MAX_NSTEP, "n_step out of range");
+    return PRISM_OK;
+}
+
+extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay_desc *rp, int64_t size,
+                                const float *mass, uint64_t seed, uint64_t offset, float beta, int64_t *out_index,
+                                float *out_weight, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    rc = check_replay_for_step(ld, rp);
+    if (rc) return rc;
+    PRISM_CHECK_ARG(size > 0 && size <= rp->capacity, "size must be in (0, capacity] (empty storage)");
+    PRISM_CHECK_ARG(out_index && (rp->sum_tree == nullptr || out_weight), "null outputs");
+    hipStream_t stream = (hipStream_t)stream_;
+    IqnArgs a;
+    fill_iqn_args(ld, a);
+    FrontArgs f;
+    f.size = size;
+    f.mass = mass;
+    f.seed = seed;
+    f.offset = offset;
+    f.rng = ld->rng_counters;
+    f.beta = beta;
+    f.use_per = rp->sum_tree != nullptr;
+    f.out_index = out_index;
+    f.out_weight = out_weight;
+    f.obs = const_cast<float *>(ld->obs);
+    f.next_obs = const_cast<float *>(ld->next_obs);
+    f.reward = const_cast<float *>(ld->reward);
+    f.gamma = const_cast<float *>(ld->gamma);
+    f.nonterminal = const_cast<uint8_t *>(ld->nonterminal);
+    f.action = const_cast<int64_t *>(ld->action);
+    {
+        ProfileScope ps_(K_FRONT, stream);
+        hipLaunchKernelGGL(step_front_kernel, dim3(ld->batch + H_DIM / 4 + PACK_BLOCKS * (1 + (ld->dims.has_target ? 1 : 0))),
+                           dim3(256), 0, stream, a, *rp, f);
+        PRISM_CHECK_LAUNCH();
+    }
+    return PRISM_OK;
+}
+
+extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_desc *rp, const int64_t *index,
+                               float alpha, float eps, prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    rc = check_replay_for_step(ld, rp);
+    if (rc) return rc;
+    PRISM_CHECK_ARG(index != nullptr, "null index");
+    hipStream_t stream = (hipStream_t)stream_;
+    IqnWs ws;
+    carve_iqn(&ld->dims, ld->batch, ld->workspace, &ws, nullptr, nullptr);
+    AdamArgs a;
+    fill_adam_args(ld, ws, a);
+    rc = prepare_norm(ld, ws, a, stream);
+    if (rc) return rc;
+    BackArgs k;
+    k.index = index;
+    k.priority = ld->out_td;
+    k.n = ld->batch;
+    k.alpha = alpha;
+    k.eps = eps;
+    k.take_abs = 1;
+    k.use_per = rp->sum_tree != nullptr;
+    k.rng = ld->rng_counters;
+    const int maxT = ld->dims.n_tau > ld->dims.n_tau_next ? ld->dims.n_tau : ld->dims.n_tau_next;
+    k.inc_per = (uint64_t)ld->batch;
+    k.inc_tau = (uint64_t)3 * maxT * ld->batch;
+    {
+        ProfileScope ps_(K_BACK, stream);
+        hipLaunchKernelGGL(step_back_kernel, dim3(1 + adam_blocks(a.n)), dim3(256), 0, stream, a, *rp, k);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

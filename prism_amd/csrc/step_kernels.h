@@ -1,0 +1,228 @@
+// Fused kernels of the whole learner step (prism/learner.py:95-125), cutting the launch count from
+// ten to six: front (PER sample + n-step gather + conv embed), tile_fwd, loss, bwd,
+// post (slab reduce + small tensors + conv backward), back (clip + Adam + priority writeback).
+// Every kernel here is a thin role dispatcher over the block-level routines of iqn_kernels.h /
+// replay_kernels.h, so fused and unfused paths execute the same arithmetic.
+#pragma once
+#include "iqn_kernels.h"
+#include "replay_kernels.h"
+
+namespace prism {
+
+struct FrontArgs {
+    int64_t size;          // stored items
+    const float *mass;     // [B] or NULL -> Philox
+    uint64_t seed, offset;
+    const uint64_t *rng;   // device counters or NULL
+    float beta;
+    int use_per;
+    int64_t *out_index;
+    float *out_weight;
+    // minibatch outputs (the static batch)
+    float *obs, *next_obs, *reward, *gamma;
+    uint8_t *nonterminal;
+    int64_t *action;
+};
+
+// blocks [0, B): one sample each — tree descent, n-step walk, row gather, conv3x3+ReLU of both
+// observations;  blocks [B, B + H/4): u = W1 g1, v = W1 beta1;  then PACK_BLOCKS (x2 with a target
+// network) blocks refresh the fragment-packed weight copies tile_fwd streams.
+__global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
+    __shared__ float s_top[TOP_NODES];
+    __shared__ float s_scratch[128];
+    __shared__ float s_obs[2][1000];
+    __shared__ float s_w[2][16 * 10 * 9];
+    __shared__ float s_b[2][16];
+    __shared__ int64_t s_i64[2];
+    __shared__ uint32_t s_flags;
+    const int B = a.B, C = a.C, tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= B + H_DIM / 4) {
+        const int pb = b - (B + H_DIM / 4);
+        if (pb < PACK_BLOCKS) pack_weights_block(a.params, a.off, a.ws.wpk[0], pb, tid);
+        else pack_weights_block(a.target_params, a.off, a.ws.wpk[1], pb - PACK_BLOCKS, tid);
+        return;
+    }
+    if (b >= B) {
+        iqn_uv_block(a, (b - B) * 4 + (tid >> 6), tid & 63);
+        return;
+    }
+    // conv weights of both networks: independent of everything else, get them in flight first
+    const float *P0 = a.params, *P1 = a.has_target ? a.target_params : a.params;
+    const int nw = 16 * C * 9;
+#pragma unroll 4
+    for (int i = tid; i < nw; i += 256) {
+        s_w[0][i] = P0[a.off.conv_w + i];
+        s_w[1][i] = P1[a.off.conv_w + i];
+    }
+    if (tid < 16) {
+        s_b[0][tid] = P0[a.off.conv_b + tid];
+        s_b[1][tid] = P1[a.off.conv_b + tid];
+    }
+    int64_t idx;
+    if (f.use_per) {
+        const int64_t cap = rp.tree_capacity;
+        const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
+#pragma unroll 8
+        for (int i = tid; i < top; i += 256) s_top[i] = rp.sum_tree[i];
+        const float p_sum = block_tree_query<false>(rp.sum_tree, cap, rp.capacity, f.size, s_scratch);
+        const float p_min = block_tree_query<true>(rp.min_tree, cap, rp.capacity, f.size, s_scratch);
+        __syncthreads();
+        if (tid == 0) {
+            if (b == 0) {
+                rp.per_state[1] = p_sum;
+                rp.per_state[2] = p_min;
+                int st = 0;
+                if (!(p_sum > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PSUM;
+                if (!(p_min > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PMIN;
+                if (st) atomicOr(rp.status, st);
+            }
+            float mass;
+            if (f.mass) {
+                mass = f.mass[b];
+            } else {
+                uint32_t r[4];
+                Philox ph(f.seed);
+                ph(f.offset + (f.rng ? f.rng[0] : 0ull) + (uint64_t)b, 0x5045524dull, r);
+                mass = (float)(0.0 + ((double)p_sum - 0.0) * u64_to_unit_double(r[0], r[1]));
+            }
+            idx = tree_descend(rp, s_top, top, mass);
+            if (idx > f.size - 1) idx = f.size - 1;
+            f.out_index[b] = idx;
+            f.out_weight[b] = pow_neg_beta(rp.sum_tree[idx | cap] / p_min, f.beta);
+            s_i64[0] = idx;
+        }
+    } else if (tid == 0) {
+        uint32_t r[4];
+        Philox ph(f.seed);
+        ph(f.offset + (f.rng ? f.rng[0] : 0ull) + (uint64_t)b, 0x554e4946ull, r);
+        idx = (int64_t)__umul64hi(((uint64_t)r[0] << 32) | r[1], (uint64_t)f.size);
+        f.out_index[b] = idx;
+        s_i64[0] = idx;
+    }
+    if (tid == 0) {
+        const NStepResult ns = nstep_walk(rp, idx);
+        s_i64[1] = ns.last;
+        s_flags = ns.flags;
+        f.reward[b] = (float)ns.ret;
+        f.gamma[b] = (float)ns.gamma;
+        f.nonterminal[b] = (ns.flags & PRISM_FLAG_DONE) ? 0 : 1;
+        f.action[b] = (int64_t)rp.action[idx];
+    }
+    __syncthreads();
+    const int O = rp.obs_elems;     // == 100 * C
+    const float *src_obs = rp.obs + s_i64[0] * O;
+    const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
+    float *d0 = f.obs + (int64_t)b * O, *d1 = f.next_obs + (int64_t)b * O;
+    for (int k = tid; k < O / 4; k += 256) {
+        const float4 x = reinterpret_cast<const float4 *>(src_obs)[k];
+        const float4 y = reinterpret_cast<const float4 *>(src_next)[k];
+        reinterpret_cast<float4 *>(d0)[k] = x;
+        reinterpret_cast<float4 *>(d1)[k] = y;
+        reinterpret_cast<float4 *>(s_obs[0])[k] = x;
+        reinterpret_cast<float4 *>(s_obs[1])[k] = y;
+    }
+    __syncthreads();
+    conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);
+    conv_embed_rows(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
+}
+
+// ------------------------------------------------------------------------------------------
+// post: 1024-thread blocks, three roles.
+//   [0, POST_SLAB_BLOCKS)                 slab sum -> grads[phi_w .. w1]
+//   [.., + n_conv)                        conv backward partials; the block that finishes last adds them up
+//   [.., + POST_SMALL_BLOCKS)             small tensors (b1, LN2, W2, b2) by 64-wide slices of H, + total loss
+// Every block leaves its sum of squares in normpart[blockIdx.x].
+// ------------------------------------------------------------------------------------------
+constexpr int POST_SLAB_BLOCKS = (SLAB / 4 + 1023) / 1024;   // 49
+constexpr int POST_SMALL_BLOCKS = H_DIM / 64;                // 2
+
+__device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
+    const int tid = threadIdx.x;
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (tid < 16) t = s_red[tid];
+    if (tid < 64) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    }
+    return t;   // valid in thread 0
+}
+
+__global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
+    __shared__ float s_red[64];
+    const int tid = threadIdx.x, B = a.B, C = a.C;
+    const int n_conv = (B + CONV_SPB - 1) / CONV_SPB;
+    const int blk = blockIdx.x;
+    float sq = 0.f;
+    if (blk < POST_SLAB_BLOCKS) {
+        const int i = blk * 1024 + tid;
+        if (i < SLAB / 4) {
+            float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
+            float4 v[7];
+#pragma unroll
+            for (int c = 1; c < 8; ++c)
+                if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * SLAB)[i];
+#pragma unroll
+            for (int c = 1; c < 8; ++c)
+                if (c < a.n_chunks) {
+                    s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
+                }
+            *reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i) = s;
+            sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+        }
+    } else if (blk < POST_SLAB_BLOCKS + n_conv) {
+        __shared__ float s_obs[CONV_SPB][1000];
+        __shared__ float s_dc[CONV_SPB][16 * 65];
+        __shared__ int s_last;
+        const int cb = blk - POST_SLAB_BLOCKS;
+        conv_bwd_partial_block(a, cb, &s_obs[0][0], &s_dc[0][0]);
+        // publish, then let the last arriver fold all partial rows: ONE lane releases after the
+        // block's stores have drained (the barrier waits for them), ONE lane acquires
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = (atomicAdd(a.ws.ticket + 1, 1u) == (unsigned)(n_conv - 1));
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (s_last) {
+            const int nk = 9 * C, n_out = 16 * nk + 16;
+            for (int o = tid; o < n_out; o += 1024) {
+                float s = 0.f;
+#pragma unroll 16
+                for (int ch = 0; ch < n_conv; ++ch) s += a.ws.convpart[(int64_t)ch * CONV_ROW + o];
+                if (o < 16 * nk) a.grads[a.off.conv_w + o] = s;
+                else a.grads[a.off.conv_b + (o - 16 * nk)] = s;
+                sq += s * s;
+            }
+            if (tid == 0) a.ws.ticket[1] = 0u;
+        }
+    } else {
+        small_tensor_block(a, blk - POST_SLAB_BLOCKS - n_conv, sq);
+    }
+    const float t = block_sum_1024(sq, s_red);
+    if (tid == 0) a.ws.normpart[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// back: block 0 = priority writeback (+ RNG counters); blocks [1, 1 + n_adam) = clip + Adam.
+// ------------------------------------------------------------------------------------------
+struct BackArgs {
+    const int64_t *index;
+    const float *priority;
+    int n;
+    float alpha, eps;
+    int take_abs, use_per;
+    uint64_t *rng;
+    uint64_t inc_per, inc_tau;
+};
+
+}  // namespace prism

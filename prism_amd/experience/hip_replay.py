@@ -91,6 +91,7 @@ class HipReplayBuffer:
         self._pending = {}        # successor Timestep.id -> (slot, id) of the stored predecessor
         self._slot_id = np.full(self.capacity, -1, np.int64)
         self._n_staged = 0
+        self._index = None
 
     # ------------------------------------------------------------------ allocation
     def _allocate(self, obs_shape):
@@ -216,7 +217,7 @@ class HipReplayBuffer:
             raise RuntimeError("Cannot sample from an empty storage.")
         self.flush()
         B = self.buffer._batch_size if batch_size is None else int(batch_size)
-        if self._index.shape[0] != B:
+        if self._index is None or self._index.shape[0] != B:
             self._alloc_batch(B)
         L, dsc, st = N.lib(), ctypes.byref(self._desc), N.current_stream_handle
         with torch.cuda.device(self.device):

@@ -27,6 +27,8 @@ class Learner:
         self.loggables = {}
         self.per_beta = None
         self.time_phases = True
+        self.fused = True
+        self.hip_graph = True
 
     def configure(self, config, collector=None, obs_shape=None, n_actions=None, process_group=None):
         (self.agent, self.timestep_collector, self.experience_buffer, self.logger,
@@ -47,12 +49,28 @@ class Learner:
         self.timesteps_since_report = self.timesteps_since_target_model_update = 0
         self.reset_loggables()
         self.device = config.device
+        # MI355X-only knobs (not Config fields): fuse the step into six launches / replay it from a hipGraph
+        self.fused = bool(getattr(config, "fused_step", True)) and \
+            getattr(config, "per_mass_rng", "philox") == "philox" and getattr(config, "tau_rng", "philox") == "philox"
+        self.hip_graph = bool(getattr(config, "hip_graph", True))
 
     # ------------------------------------------------------------------ the hot path
     def step(self, timesteps_this_iteration=0, eager=False):
         """learner.py:95-125.  All work is enqueued on the current HIP stream; nothing here
         synchronises with the device."""
         buf, agent, tp = self.experience_buffer, self.agent, self.time_phases
+        if self.fused and hasattr(agent, "step_fused") and hasattr(buf, "flush"):
+            buf.flush()
+            if self.use_per:
+                buf.buffer._sampler._beta = 0.5
+            td = agent.step_fused(buf, eager=eager, use_graph=self.hip_graph)
+            self.cumulative_model_updates += 1
+            self.timesteps_since_target_model_update += timesteps_this_iteration
+            if self.use_target_network and \
+                    self.timesteps_since_target_model_update >= self.target_network_update_period:
+                agent.sync_target_model()
+                self.timesteps_since_target_model_update = 0
+            return td
         t0 = time.perf_counter() if tp else 0.0
         if self.cumulative_model_updates == 1 and agent.get_static_batch() is not None:
             buf.set_static_batch(agent.get_static_batch())

@@ -1,0 +1,35 @@
+"""Diagnostic: in-kernel phase stamps (s_memtime) of tile_fwd / bwd.  GPU box only; PRISM_DBG=8."""
+import os, sys, contextlib, io
+os.environ["PRISM_DBG"] = os.environ.get("PRISM_DBG", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from prism_amd.config import baseline_config
+from prism_amd.learner import Learner
+from prism_amd.synthetic import fill_replay
+cfg = baseline_config(int(sys.argv[1]) if len(sys.argv) > 1 else 2, device="cuda:0")
+cfg.hip_graph = False
+ln = Learner()
+with contextlib.redirect_stdout(io.StringIO()):
+    ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
+fill_replay(ln.experience_buffer, 20000 if cfg.experience_replay_capacity > 20000 else cfg.experience_replay_capacity, seed=0)
+ag = ln.agent
+for _ in range(5): ln.step(eager=True)
+st = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda:0")
+ag._desc.dbg_stamps = st.data_ptr()
+# tile_fwd and bwd share the stamp buffer: run one step, read after each kernel is impossible -> use
+# the fact that bwd overwrites slots 0..4 of its own blocks; dump both by running twice with masks
+def run():
+    st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 16)
+s = run()
+f = s[:256, :8].astype(np.float64)
+names = ["wphi issue+row setup", "cos+barrier", "phi mfma+ytile", "w1 issue+barrier", "layernorm", "trunk mfma", "fold", "ln128+head"]
+print("tile_fwd (median over 256 workgroups, shader-clock ticks):")
+for k in range(7):
+    print(f"   {names[k]:24s} {np.median(f[:, k + 1] - f[:, k]):9.0f}")
+print(f"   total {np.median(f[:, 7] - f[:, 0]):9.0f}   start spread {f[:, 0].max() - f[:, 0].min():9.0f}   end spread {f[:, 7].max() - f[:, 7].min():9.0f}")
+nb = int((s[:, 8] != 0).sum())
+b = s[:nb, 8:13].astype(np.float64)
+print(f"bwd ({nb} workgroups):")
+for k, name in enumerate(["consts", "tile loop", "barrier", "reduce+write"]):
+    print(f"   {name:24s} {np.median(b[:, k + 1] - b[:, k]):9.0f}")
+print(f"   total {np.median(b[:, 4] - b[:, 0]):9.0f}   start spread {b[:, 0].max() - b[:, 0].min():9.0f}  end spread {b[:, 4].max() - b[:, 4].min():9.0f}")
