@@ -138,7 +138,8 @@ def main():
 
     cfg = baseline_config(args.config, device=dev)
     if args.config == 4:
-        cfg.experience_replay_capacity = 10_000_000 // world
+        from prism_amd.dist import shard_capacity
+        cfg.experience_replay_capacity = shard_capacity(10_000_000, world)
     cfg.per_seed_offset = rank
     cfg.hip_graph = not args.no_graph
     learner = Learner()
@@ -146,8 +147,8 @@ def main():
         learner.configure(cfg, obs_shape=(10, 10, 4), n_actions=6, process_group=pg)
     learner.time_phases = False
     buf, agent = learner.experience_buffer, learner.agent
-    buf.seed = cfg.seed + 7919 * rank
-    agent.seed = cfg.seed + 104729 * rank
+    from prism_amd.dist import rank_seeds
+    _, buf.seed, agent.seed = rank_seeds(cfg.seed, rank)
     fill_replay(buf, buf.capacity, seed=rank)
 
     def sync():

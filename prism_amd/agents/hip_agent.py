@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from prism_amd import _native as N
+from prism_amd import dist as pdist
 
 
 class HipAdam:
@@ -283,7 +284,7 @@ class HipAgent:
         with torch.cuda.device(self.device):
             N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), N.current_stream_handle()), "prism_learner_fwd_bwd")
             if self.world > 1:
-                torch.distributed.all_reduce(self.grads, group=self.pg)
+                pdist.allreduce_grads(self.grads, self.pg)
             N.check(L.prism_learner_clip_adam(ctypes.byref(d), N.current_stream_handle()), "prism_learner_clip_adam")
         self._keep = keep
         self._static_total_loss = self.scalars[0]
@@ -318,7 +319,7 @@ class HipAgent:
             N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), st()), "prism_learner_fwd_bwd")
             d.embed_done = 0
         if part == "all" and self.world > 1:
-            torch.distributed.all_reduce(self.grads, group=self.pg)
+            pdist.allreduce_grads(self.grads, self.pg)
         if part in ("all", "back"):
             smp = buf.buffer._sampler
             N.check(L.prism_step_back(ctypes.byref(d), rp, N.ptr(buf._index), smp._alpha, smp._eps, st()),
@@ -367,7 +368,7 @@ class HipAgent:
         with torch.cuda.graph(g1):
             self._launch_fused(buf, d, "front")
         g1.replay()
-        torch.distributed.all_reduce(self.grads, group=self.pg)
+        pdist.allreduce_grads(self.grads, self.pg)
         with torch.cuda.graph(g2):
             self._launch_fused(buf, d, "back")
         g2.replay()
@@ -378,7 +379,7 @@ class HipAgent:
             g[0].replay()
         else:
             g[0].replay()
-            torch.distributed.all_reduce(self.grads, group=self.pg)
+            pdist.allreduce_grads(self.grads, self.pg)
             g[1].replay()
 
     @torch.no_grad()

@@ -1,0 +1,84 @@
+"""No GPU needed: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/prism_hip.h declares; argument checking works without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from tests import helpers as H
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from prism_amd import _native as N
+    if not os.path.exists(N.LIB_PATH):
+        g.build()
+    return N.lib()
+
+
+def declared_symbols():
+    src = open(os.path.join(H.ROOT, "include", "prism_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(prism_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from prism_amd import _native as N
+    names = declared_symbols()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(N.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in prism_hip.h but not exported"
+        assert n in N.SIGNATURES, f"{n} has no ctypes signature in prism_amd/_native.py"
+    assert set(N.SIGNATURES) == set(names)
+    assert lib.prism_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the C sizes (guards against silent field drift)."""
+    from prism_amd import _native as N
+    assert ctypes.sizeof(N.ReplayDesc) == 8 + 8 + 4 + 4 + 11 * 8 + 16 * 8
+    assert ctypes.sizeof(N.ModelDims) == 16 * 4 + 4 * 4
+    assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
+    assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4
+    # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40)
+    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 7 * 8 + 8 + 40
+
+
+def test_argument_checks_without_device(lib):
+    from prism_amd import _native as N
+    assert lib.prism_per_sample(None, 10, 4, None, 0, 0, 0.5, None, None, None) == -1
+    assert b"null descriptor" in lib.prism_last_error()
+    d = N.ReplayDesc()
+    d.capacity, d.tree_capacity = 100, 64
+    assert lib.prism_replay_init(ctypes.byref(d), None) == -1
+    assert b"tree_capacity" in lib.prism_last_error()
+    dims = N.ModelDims()
+    assert lib.prism_learner_workspace_bytes(ctypes.byref(dims), 256) == 0          # unsupported dims
+    assert lib.prism_learner_supported(ctypes.byref(dims), 256) == -3
+    dims.in_channels, dims.n_actions, dims.embed_dim, dims.use_iqn = 4, 6, 1024, 1
+    dims.n_basis, dims.iqn_layers, dims.iqn_width, dims.n_tau, dims.n_tau_next, dims.use_layer_norm = 64, 1, 128, 8, 8, 1
+    assert lib.prism_learner_supported(ctypes.byref(dims), 256) == 0
+    assert lib.prism_learner_workspace_bytes(ctypes.byref(dims), 256) > 8 * 2 ** 20
+    assert lib.prism_learner_supported(ctypes.byref(dims), 255) == -3                # B*T not a multiple of 16
+
+
+def test_product_never_imports_oracle_and_has_no_cpu_path():
+    import subprocess
+    import sys
+    root = os.path.join(H.ROOT, "prism_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} references the oracle"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from prism_amd.config import baseline_config\n"
+            "from prism_amd.factory import exp_buffer_factory\n"
+            "from prism_amd._native import NativeLibraryError\n"
+            "try:\n    exp_buffer_factory.build_exp_buffer(baseline_config(2, device='cpu'))\n"
+            "except NativeLibraryError as e:\n    print('LOUD', e)\n" % H.ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "LOUD" in out.stdout, out.stdout + out.stderr

@@ -263,12 +263,28 @@ def gen_nstep():
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
-    which = sys.argv[1:] or (list(CASES) + ["nstep"])
+    which = sys.argv[1:] or (list(CASES) + ["nstep", "config"])
     for name in which:
         if name == "nstep":
             gen_nstep()
+        elif name == "config":
+            gen_config_snapshot()
         else:
             gen_update_case(name, *CASES[name])
+
+
+
+
+def gen_config_snapshot():
+    """Field names / order / preset values of the reference's Config, as data."""
+    import dataclasses
+    import json
+    from prism.config import Config, DEFAULT_CONFIG, MINATAR_CONFIG
+    snap = {"fields": [f.name for f in dataclasses.fields(Config)],
+            "DEFAULT_CONFIG": DEFAULT_CONFIG.__dict__, "MINATAR_CONFIG": MINATAR_CONFIG.__dict__}
+    with open(os.path.join(OUT, "config_presets.json"), "w") as f:
+        json.dump(snap, f, indent=1, sort_keys=True)
+    print("config_presets:", len(snap["fields"]), "fields")
 
 
 if __name__ == "__main__":
