@@ -43,6 +43,7 @@ struct IqnPass {
     int n_tiles;          // B*T/16
     int save;             // current-state pass: keep what backward needs
     int stream_id;        // 0 cur, 1 next-online, 2 next-target
+    int kind;             // 0: IQN quantile rows, 1: Q-head rows (w1_pk = packed W1 of all heads, head-major)
 };
 
 struct IqnWs {           // workspace pointers (device)
@@ -52,6 +53,15 @@ struct IqnWs {           // workspace pointers (device)
     float *zcur, *zon, *ztg;
     float *dq, *c1, *c2, *dpre1, *Sb, *Pb, *Db, *lossw;
     float *de_iqn;
+    // Q heads (rows indexed head*B + sample)
+    float *q_mu1, *q_rstd1, *q_pre1, *q_xhat2, *q_rstd2;
+    float *zq_cur, *zq_on, *zq_tg;
+    float *q_dq, *q_c1, *q_c2, *q_dpre1, *q_Sb, *q_Pb, *q_Db, *q_lossw;
+    float *q_uv;         // [heads][2][H]
+    float *q_kappa;      // [heads] Theil gradient factors, [heads] = theil value
+    float *q_wpk[2];     // [online, target] packed W1 of every head
+    float *de_q;         // [B][E] embedding gradient from the Q heads
+    float *q_slabs;      // [n_chunks][heads][Q_SLAB]
     float *slabs;        // [n_chunks][SLAB]
     float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
     float *normpart;     // [NORM_SLOTS]
@@ -62,11 +72,13 @@ constexpr int SLAB = E_DIM * K_BASIS + E_DIM + E_DIM + E_DIM + H_DIM * E_DIM;  /
 constexpr int NORM_SLOTS = 1280;
 
 struct IqnArgs {
-    IqnPass pass[3];
+    IqnPass pass[6];
     int n_pass;
     int B, A, C, T, Tn;
     int n_chunks;          // row chunks of the backward
     int has_target, double_q, propagate_grad;
+    int use_iqn, n_heads;  // Q ensemble: 0 = none
+    float q_w, theil_coef;
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
     unsigned long long *stamps;   // diagnostic builds only: [block][16] shader-clock stamps (dbg & 8)
     float huber_k, dist_w;
@@ -80,7 +92,7 @@ struct IqnArgs {
     const uint64_t *rng;   // device counters {PER draws, tau draws} or NULL
     float *tau_out;        // [3][maxT*B] or NULL
     int maxT;
-    float *out_dl, *out_td, *out_scalars;
+    float *out_dl, *out_ql, *out_td, *out_scalars;
     float *grads;
     IqnWs ws;
 };
@@ -156,20 +168,16 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
     }
 }
 
+__device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red);
+
 __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
     __shared__ float s_obs[1024];
     __shared__ float s_w[16 * 10 * 9];
     __shared__ float s_b[16];
     const int B = a.B, C = a.C;
     const int blk = blockIdx.x, tid = threadIdx.x;
-    if (blk >= 2 * B + H_DIM / 4) {
-        const int pb = blk - (2 * B + H_DIM / 4);
-        if (pb < PACK_BLOCKS) pack_weights_block(a.params, a.off, a.ws.wpk[0], pb, tid);
-        else pack_weights_block(a.target_params, a.off, a.ws.wpk[1], pb - PACK_BLOCKS, tid);
-        return;
-    }
     if (blk >= 2 * B) {
-        iqn_uv_block(a, (blk - 2 * B) * 4 + (tid >> 6), tid & 63);
+        embed_extra_block(a, blk - 2 * B, s_b);      // defined in step_kernels.h (front_extra_block)
         return;
     }
     const bool is_next = blk >= B;
@@ -196,10 +204,167 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
     } while (0)
 
 // ------------------------------------------------------------------------------------------
-// tile_fwd: 512 threads = 8 waves, one 16-row tile per workgroup.
+// tile_fwd: 512 threads = 8 waves, one 16-row tile per workgroup.  Two kinds of tile share the tail
+// [LayerNorm(1024) -> trunk GEMM (K = 1024) -> ReLU -> LayerNorm(128) -> head]:
+//   kind 0 (IQN, iqn_model.py:48-93)      rows = (sample, tau); input = ReLU(phi(cos basis)) * e
+//   kind 1 (Q head, q_ensemble.py:25-48)  rows = samples of one ensemble head; input = e
 // ------------------------------------------------------------------------------------------
 constexpr int PS = H_DIM + 4;   // row stride of the per-wave trunk partials
 constexpr int TILE_FWD_LDS_FLOATS = 16 * YS + 16 * CS + 16 * HS + 64 + 8 * 16 * PS;
+
+struct TrunkParams {      // one LN -> Linear -> ReLU -> LN -> Linear stack
+    const float *ln1_g, *ln1_b, *b1, *ln2_g, *ln2_b, *w2, *b2;
+    const float4 *w1pk;   // fragment-packed W1 of this stack
+};
+struct TileSave {         // what the backward of this tile needs (NULL pointers: nothing saved)
+    float *mu1, *rstd1, *pre1, *xhat2, *rstd2;
+    int64_t row0;         // index of the tile's first row in those arrays
+};
+
+// Tail shared by both kinds.  On entry: ytile holds the 16 x 1024 input rows (all waves' writes
+// issued, not yet synchronised), bt[0..3] hold this wave's K slice of output tiles 0..3.
+__device__ __forceinline__ void tile_trunk_head(const IqnArgs &a, const TrunkParams &tp, const TileSave &sv,
+                                                float *ytile, float *h1, float *part, float4 (&bt)[4][8],
+                                                float *z_out, int A) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
+    float4 lng[4], lnb[4];      // LayerNorm(1024) affine for this lane's 16 columns: in flight across the barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *pg = tp.ln1_g + (i * 64 + lane) * 4, *pb = tp.ln1_b + (i * 64 + lane) * 4;
+        lng[i] = float4{pg[0], pg[1], pg[2], pg[3]};     // head tensors are only 4-byte aligned
+        lnb[i] = float4{pb[0], pb[1], pb[2], pb[3]};
+    }
+    lds_barrier();
+
+    PRISM_STAMP(3);
+    // ---- LayerNorm(1024): wave w owns rows 2w, 2w+1; normalise in place ------------------------
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int m = 2 * w + rr;
+        float4 x[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = *reinterpret_cast<const float4 *>(&ytile[m * YS + (i * 64 + lane) * 4]);
+            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+        }
+        const float mean = wave_sum(s) * (1.0f / E_DIM);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+            v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+        }
+        const float var = wave_sum(v) * (1.0f / E_DIM);
+        const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = (i * 64 + lane) * 4;
+            const float4 gg = lng[i], bb = lnb[i];
+            float4 y;
+            y.x = x[i].x * rstd * gg.x + bb.x;
+            y.y = x[i].y * rstd * gg.y + bb.y;
+            y.z = x[i].z * rstd * gg.z + bb.z;
+            y.w = x[i].w * rstd * gg.w + bb.w;
+            *reinterpret_cast<float4 *>(&ytile[m * YS + n]) = y;
+        }
+        if (sv.mu1 && lane == 0) {
+            sv.mu1[sv.row0 + m] = mean;
+            sv.rstd1[sv.row0 + m] = rstd;
+        }
+    }
+    lds_barrier();
+
+    PRISM_STAMP(4);
+    // ---- trunk GEMM (16 x 128, K = 1024), K split over the 8 waves ------------------------------
+    {
+        float4 at[8];   // A fragments of this wave's K slice, reused by all 8 output tiles
+#pragma unroll
+        for (int q = 0; q < 8; ++q) at[q] = *reinterpret_cast<const float4 *>(&ytile[li * YS + 128 * w + 16 * q + 4 * g]);
+        float *mypart = part + w * 16 * PS;
+#pragma unroll
+        for (int np = 0; np < 4; ++np) {        // output tiles 2np, 2np+1: ring slots (2np)&3, (2np+1)&3
+            const int s0 = (2 * np) & 3, s1 = (2 * np + 1) & 3;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc0 = mfma16(at[q].x, bt[s0][q].x, acc0);
+                acc1 = mfma16(at[q].x, bt[s1][q].x, acc1);
+                acc0 = mfma16(at[q].y, bt[s0][q].y, acc0);
+                acc1 = mfma16(at[q].y, bt[s1][q].y, acc1);
+                acc0 = mfma16(at[q].z, bt[s0][q].z, acc0);
+                acc1 = mfma16(at[q].z, bt[s1][q].z, acc1);
+                acc0 = mfma16(at[q].w, bt[s0][q].w, acc0);
+                acc1 = mfma16(at[q].w, bt[s1][q].w, acc1);
+            }
+            if (np < 2) {                        // refill the two slots just consumed with tiles +4
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    bt[s0][q] = W1pk[((2 * np + 4) * 8 + q) * 64];
+                    bt[s1][q] = W1pk[((2 * np + 5) * 8 + q) * 64];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mypart[(4 * g + r) * PS + 32 * np + li] = acc0[r];
+                mypart[(4 * g + r) * PS + 32 * np + 16 + li] = acc1[r];
+            }
+        }
+    }
+    // head operands: issue now, consume after two more barriers
+    const float g2a = tp.ln2_g[lane], g2b = tp.ln2_g[lane + 64], b2a = tp.ln2_b[lane], b2b = tp.ln2_b[lane + 64];
+    float w2a[16], w2b[16], b2r[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa)
+        if (aa < A) {
+            w2a[aa] = tp.w2[aa * H_DIM + lane];
+            w2b[aa] = tp.w2[aa * H_DIM + 64 + lane];
+            b2r[aa] = tp.b2[aa];
+        }
+    const float b1v0 = tp.b1[tid & 127];
+    lds_barrier();
+    PRISM_STAMP(5);
+    // fold the 8 K-slices in fixed order, + bias, ReLU
+    for (int idx = tid; idx < 16 * H_DIM; idx += 512) {
+        const int m = idx >> 7, h = idx & 127;
+        float s = part[m * PS + h];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) s += part[(ww * 16 + m) * PS + h];
+        const float pre = s + b1v0;             // h == tid & 127 for every idx of this thread
+        h1[m * HS + h] = fmaxf(pre, 0.f);
+        if (sv.pre1) sv.pre1[(sv.row0 + m) * H_DIM + h] = pre;
+    }
+    lds_barrier();
+
+    PRISM_STAMP(6);
+    // ---- LayerNorm(128) + head (128 -> A): wave w owns rows 2w, 2w+1 ---------------------------
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int m = 2 * w + rr;
+        float x0 = h1[m * HS + lane], x1 = h1[m * HS + 64 + lane];
+        const float mean = wave_sum(x0 + x1) * (1.0f / H_DIM);
+        x0 -= mean;
+        x1 -= mean;
+        const float var = wave_sum(x0 * x0 + x1 * x1) * (1.0f / H_DIM);
+        const float rstd = 1.0f / sqrtf(var + LN_EPS);
+        const float xh0 = x0 * rstd, xh1 = x1 * rstd;
+        const float y0 = xh0 * g2a + b2a, y1 = xh1 * g2b + b2b;
+        if (sv.xhat2) {
+            sv.xhat2[(sv.row0 + m) * H_DIM + lane] = xh0;
+            sv.xhat2[(sv.row0 + m) * H_DIM + 64 + lane] = xh1;
+            if (lane == 0) sv.rstd2[sv.row0 + m] = rstd;
+        }
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa)
+            if (aa < A) {
+                const float z = wave_sum(y0 * w2a[aa] + y1 * w2b[aa]) + b2r[aa];
+                if (lane == 0) z_out[(int64_t)m * A + aa] = z;
+            }
+    }
+    PRISM_STAMP(7);
+}
 
 __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -207,7 +372,6 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     float *cost = ytile + 16 * YS;
     float *h1 = cost + 16 * CS;
     float *rowf = h1 + 16 * HS;                 // [0,16) tau
-    int *rowb = reinterpret_cast<int *>(rowf + 48);  // [16] sample of each row
     float *part = rowf + 64;                    // [8 waves][16 rows][PS] K-split partials of the trunk GEMM
 
     int tile = blockIdx.x, pi = 0;
@@ -216,15 +380,48 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
         ++pi;
     }
     const IqnPass ps = a.pass[pi];
-    const int B = a.B, A = a.A, T = ps.T;
+    const int B = a.B, A = a.A;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int li = lane & 15, g = lane >> 4;
-    const int r0 = tile * 16;
     const float *P = ps.params;
+    float4 bt[4][8];       // [ring slot][q]: trunk B operand, B[k = 128w + 16q + 4g + jj][h = 16nt + li]
+    PRISM_STAMP(0);
 
+    if (ps.kind == 1) {
+        // ---- Q-head tile: 16 samples of ensemble head hd; input rows are the embeddings -----------
+        const int tiles_per_head = B / 16;
+        const int hd = tile / tiles_per_head, b0 = (tile - hd * tiles_per_head) * 16;
+        const float *Ph = P + a.off.head_base + (int64_t)hd * a.off.head_stride;
+        TrunkParams tp{Ph + a.off.h_ln1_g, Ph + a.off.h_ln1_b, Ph + a.off.h_b1, Ph + a.off.h_ln2_g, Ph + a.off.h_ln2_b,
+                       Ph + a.off.h_w2, Ph + a.off.h_b2,
+                       reinterpret_cast<const float4 *>(ps.w1_pk + (size_t)hd * H_DIM * E_DIM)};
+        const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bt[nt][q] = W1pk[(nt * 8 + q) * 64];
+        // rows: 16 x 4 KB contiguous in e -> LDS (wave w copies rows 2w, 2w+1)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int m = 2 * w + rr;
+            const float4 *src = reinterpret_cast<const float4 *>(ps.e + (int64_t)(b0 + m) * E_DIM);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4 *>(&ytile[m * YS + (i * 64 + lane) * 4]) = src[i * 64 + lane];
+        }
+        const int64_t row0 = (int64_t)hd * B + b0;
+        TileSave sv{ps.save ? a.ws.q_mu1 : nullptr, a.ws.q_rstd1, ps.save ? a.ws.q_pre1 : nullptr,
+                    ps.save ? a.ws.q_xhat2 : nullptr, a.ws.q_rstd2, row0};
+        PRISM_STAMP(1);
+        PRISM_STAMP(2);
+        tile_trunk_head(a, tp, sv, ytile, h1, part, bt, ps.z_out + row0 * A, A);
+        return;
+    }
+
+    const int T = ps.T;
+    const int r0 = tile * 16;
     // Weights do not depend on anything computed here: put the whole phi B operand of this wave
     // (8 column tiles x K = 64) in flight before the first barrier.
-    PRISM_STAMP(0);
     const float *bphi = P + a.off.phi_b;
     float4 bq[8][4];       // [tile][q]: B[k = 16q + 4g + jj][n = 128w + 16nt + li], 1 KB contiguous per wave load
     {
@@ -232,10 +429,8 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                bq[nt][q] = (a.dbg & 2) ? float4{1.f, 2.f, 3.f, 4.f} : src[(nt * 4 + q) * 64];
+            for (int q = 0; q < 4; ++q) bq[nt][q] = src[(nt * 4 + q) * 64];
     }
-
     // phi epilogue operands (bias, embedded observation of the row group's sample): also early
     const float *erow = ps.e + (int64_t)((r0 + 4 * g) / T) * E_DIM;   // rows 4g..4g+3 share a sample (T % 4 == 0)
     float pb_[8], pe_[8];
@@ -258,7 +453,6 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
         }
         if (a.tau_out) a.tau_out[(int64_t)ps.stream_id * a.maxT * B + (int64_t)t * B + b] = tau;
         rowf[tid] = tau;
-        rowb[tid] = b;
     }
     lds_barrier();
     // cos basis: c[m][k] = cos(tau * (k+1) * pi), two fp32 multiplies as torch does (iqn_model.py:90-92)
@@ -272,11 +466,12 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     lds_barrier();
 
     PRISM_STAMP(1);
+    TrunkParams tp{P + a.off.iqn_ln1_g, P + a.off.iqn_ln1_b, P + a.off.iqn_b1, P + a.off.iqn_ln2_g, P + a.off.iqn_ln2_b,
+                   P + a.off.iqn_w2,    P + a.off.iqn_b2,    reinterpret_cast<const float4 *>(ps.w1_pk)};
     // Trunk weights: wave w owns the K slice [128w, 128w+128) for ALL 128 outputs.  The first four
     // output tiles' B operand is requested tile by tile WHILE the phi tiles are being consumed, so the
     // weight stream never pauses between the two GEMMs.
-    const float4 *W1pk = reinterpret_cast<const float4 *>(ps.w1_pk) + (size_t)w * 8 * 8 * 64 + lane;
-    float4 bt[4][8];       // [ring slot][q]: B[k = 128w + 16q + 4g + jj][h = 16nt + li]
+    const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
     // ---- phi GEMM (16 x 1024, K = 64) + bias + ReLU + Hadamard with e -> ytile ----------------
     // two column tiles at a time: their MFMA chains interleave, so no chain waits on itself
     {
@@ -305,154 +500,13 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
                 ytile[(4 * g + r) * YS + n1] = fmaxf(acc1[r] + bias1, 0.f) * ev1;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)     // one trunk tile per consumed phi pair
-                bt[np][q] = (a.dbg & 1) ? float4{1.f, 2.f, 3.f, 4.f} : W1pk[(np * 8 + q) * 64];
+            for (int q = 0; q < 8; ++q) bt[np][q] = W1pk[(np * 8 + q) * 64];   // one trunk tile per consumed phi pair
         }
     }
     PRISM_STAMP(2);
-    float4 lng[4], lnb[4];      // LayerNorm(1024) affine for this lane's 16 columns: in flight across the barrier
-    {
-        const float *g1 = P + a.off.iqn_ln1_g, *be1 = P + a.off.iqn_ln1_b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lng[i] = *reinterpret_cast<const float4 *>(g1 + (i * 64 + lane) * 4);
-            lnb[i] = *reinterpret_cast<const float4 *>(be1 + (i * 64 + lane) * 4);
-        }
-    }
-    lds_barrier();
-
-    PRISM_STAMP(3);
-    // ---- LayerNorm(1024): wave w owns rows 2w, 2w+1; normalise in place ------------------------
-    {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int m = 2 * w + rr;
-            float4 x[4];
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                x[i] = *reinterpret_cast<const float4 *>(&ytile[m * YS + (i * 64 + lane) * 4]);
-                s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-            }
-            const float mean = wave_sum(s) * (1.0f / E_DIM);
-            float v = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-                v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
-            }
-            const float var = wave_sum(v) * (1.0f / E_DIM);
-            const float rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = (i * 64 + lane) * 4;
-                const float4 gg = lng[i], bb = lnb[i];
-                float4 y;
-                y.x = x[i].x * rstd * gg.x + bb.x;
-                y.y = x[i].y * rstd * gg.y + bb.y;
-                y.z = x[i].z * rstd * gg.z + bb.z;
-                y.w = x[i].w * rstd * gg.w + bb.w;
-                *reinterpret_cast<float4 *>(&ytile[m * YS + n]) = y;
-            }
-            if (ps.save && lane == 0) {
-                a.ws.mu1[r0 + m] = mean;
-                a.ws.rstd1[r0 + m] = rstd;
-            }
-        }
-    }
-    lds_barrier();
-
-    PRISM_STAMP(4);
-    // ---- trunk GEMM (16 x 128, K = 1024), K split over the 8 waves ------------------------------
-    {
-        float4 at[8];   // A fragments of this wave's K slice, reused by all 8 output tiles
-#pragma unroll
-        for (int q = 0; q < 8; ++q) at[q] = *reinterpret_cast<const float4 *>(&ytile[li * YS + 128 * w + 16 * q + 4 * g]);
-        float *mypart = part + w * 16 * PS;
-#pragma unroll
-        for (int np = 0; np < 4; ++np) {        // output tiles 2np, 2np+1: ring slots (2np)&3, (2np+1)&3
-            const int s0 = (2 * np) & 3, s1 = (2 * np + 1) & 3;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < ((a.dbg & 4) ? 1 : 8); ++q) {
-                acc0 = mfma16(at[q].x, bt[s0][q].x, acc0);
-                acc1 = mfma16(at[q].x, bt[s1][q].x, acc1);
-                acc0 = mfma16(at[q].y, bt[s0][q].y, acc0);
-                acc1 = mfma16(at[q].y, bt[s1][q].y, acc1);
-                acc0 = mfma16(at[q].z, bt[s0][q].z, acc0);
-                acc1 = mfma16(at[q].z, bt[s1][q].z, acc1);
-                acc0 = mfma16(at[q].w, bt[s0][q].w, acc0);
-                acc1 = mfma16(at[q].w, bt[s1][q].w, acc1);
-            }
-            if (np < 2 && !(a.dbg & 1)) {        // refill the two slots just consumed with tiles +4
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    bt[s0][q] = W1pk[((2 * np + 4) * 8 + q) * 64];
-                    bt[s1][q] = W1pk[((2 * np + 5) * 8 + q) * 64];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mypart[(4 * g + r) * PS + 32 * np + li] = acc0[r];
-                mypart[(4 * g + r) * PS + 32 * np + 16 + li] = acc1[r];
-            }
-        }
-    }
-    // head operands: issue now, consume after two more barriers
-    const float *g2 = P + a.off.iqn_ln2_g, *be2 = P + a.off.iqn_ln2_b;
-    const float *W2 = P + a.off.iqn_w2, *b2 = P + a.off.iqn_b2;
-    const float g2a = g2[lane], g2b = g2[lane + 64], b2a = be2[lane], b2b = be2[lane + 64];
-    float w2a[16], w2b[16], b2r[16];
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa)
-        if (aa < A) {
-            w2a[aa] = W2[aa * H_DIM + lane];
-            w2b[aa] = W2[aa * H_DIM + 64 + lane];
-            b2r[aa] = b2[aa];
-        }
-    const float b1v0 = P[a.off.iqn_b1 + (tid & 127)];
-    lds_barrier();
-    PRISM_STAMP(5);
-    // fold the 8 K-slices in fixed order, + bias, ReLU
-    for (int idx = tid; idx < 16 * H_DIM; idx += 512) {
-        const int m = idx >> 7, h = idx & 127;
-        float s = part[m * PS + h];
-#pragma unroll
-        for (int ww = 1; ww < 8; ++ww) s += part[(ww * 16 + m) * PS + h];
-        const float pre = s + b1v0;             // h == tid & 127 for every idx of this thread
-        h1[m * HS + h] = fmaxf(pre, 0.f);
-        if (ps.save) a.ws.pre1[(int64_t)(r0 + m) * H_DIM + h] = pre;
-    }
-    lds_barrier();
-
-    PRISM_STAMP(6);
-    // ---- LayerNorm(128) + head (128 -> A): wave w owns rows 2w, 2w+1 ---------------------------
-    {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int m = 2 * w + rr;
-            float x0 = h1[m * HS + lane], x1 = h1[m * HS + 64 + lane];
-            const float mean = wave_sum(x0 + x1) * (1.0f / H_DIM);
-            x0 -= mean;
-            x1 -= mean;
-            const float var = wave_sum(x0 * x0 + x1 * x1) * (1.0f / H_DIM);
-            const float rstd = 1.0f / sqrtf(var + LN_EPS);
-            const float xh0 = x0 * rstd, xh1 = x1 * rstd;
-            const float y0 = xh0 * g2a + b2a, y1 = xh1 * g2b + b2b;
-            if (ps.save) {
-                a.ws.xhat2[(int64_t)(r0 + m) * H_DIM + lane] = xh0;
-                a.ws.xhat2[(int64_t)(r0 + m) * H_DIM + 64 + lane] = xh1;
-                if (lane == 0) a.ws.rstd2[r0 + m] = rstd;
-            }
-#pragma unroll
-            for (int aa = 0; aa < 16; ++aa)
-                if (aa < A) {
-                    const float z = wave_sum(y0 * w2a[aa] + y1 * w2b[aa]) + b2r[aa];
-                    if (lane == 0) ps.z_out[(int64_t)(r0 + m) * A + aa] = z;
-                }
-        }
-    }
-    PRISM_STAMP(7);
+    TileSave sv{ps.save ? a.ws.mu1 : nullptr, a.ws.rstd1, ps.save ? a.ws.pre1 : nullptr, ps.save ? a.ws.xhat2 : nullptr,
+                a.ws.rstd2, (int64_t)r0};
+    tile_trunk_head(a, tp, sv, ytile, h1, part, bt, ps.z_out + (int64_t)r0 * A, A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,7 +601,7 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
         if (lane < T) s_dq[lane] = gq * scale;
         if (lane == 0) {
             a.out_dl[b] = dl;
-            if (a.out_td) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
+            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
             a.ws.lossw[b] = dl * wb;
         }
     }
@@ -852,7 +906,8 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
     for (int i = tid; i < ns * E_DIM; i += 1024) {
         const int s = i >> 10, n = i & 1023;
         const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
-        const float d = a.propagate_grad ? a.ws.de_iqn[o] : 0.f;
+        float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
+        if (a.n_heads > 0) d += a.ws.de_q[o];
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
@@ -966,9 +1021,11 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
 #pragma unroll
         for (int p = 0; p < 16; ++p) l += s_lw[p];
         l = l / (float)B;       // mean_b(dl_b * w_b)  (agent.py:58-64)
-        a.out_scalars[0] = l;
         a.out_scalars[1] = l;
-        a.out_scalars[2] = 0.f;
+        if (a.n_heads == 0) {
+            a.out_scalars[0] = l;
+            a.out_scalars[2] = 0.f;
+        }
     }
 }
 

@@ -147,12 +147,20 @@ struct Carver {
 
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
-    if (!d->use_iqn || d->n_heads != 0) return PRISM_ERR_UNSUPPORTED;
-    if (d->embed_dim != E_DIM || d->n_basis != K_BASIS || d->iqn_layers != 1 || d->iqn_width != H_DIM ||
-        !d->use_layer_norm)
-        return PRISM_ERR_UNSUPPORTED;
-    if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
-    if (B < 1 || B > SMALL_MAX_B || (B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
+    if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
+    if (d->embed_dim != E_DIM || !d->use_layer_norm) return PRISM_ERR_UNSUPPORTED;
+    if (d->use_iqn) {
+        if (d->n_basis != K_BASIS || d->iqn_layers != 1 || d->iqn_width != H_DIM) return PRISM_ERR_UNSUPPORTED;
+        if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
+        if ((B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
+    }
+    if (d->n_heads != 0) {
+        // ensemble / DQN heads of the form LN -> Linear(1024,128) -> ReLU -> LN -> Linear(128,A)
+        if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || d->head_width != H_DIM)
+            return PRISM_ERR_UNSUPPORTED;
+        if (B % 16 || B / 16 > 4 * BWD_CHUNKS * QB_MAX_TILES) return PRISM_ERR_UNSUPPORTED;
+    }
+    if (B < 1 || B > SMALL_MAX_B) return PRISM_ERR_UNSUPPORTED;
     if (d->n_actions < 1 || d->n_actions > 16 || d->in_channels < 1 || d->in_channels > 10) return PRISM_ERR_UNSUPPORTED;
     return PRISM_OK;
 }
@@ -191,6 +199,29 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.slabs = c.f((size_t)N_CHUNKS * SLAB);
     w.convpart = c.f((size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW);
     w.normpart = c.f(NORM_SLOTS);
+    {
+        const size_t Hd = d->n_heads, RQ = Hd * (size_t)B;
+        w.q_mu1 = c.f(RQ);
+        w.q_rstd1 = c.f(RQ);
+        w.q_pre1 = c.f(RQ * H_DIM);
+        w.q_xhat2 = c.f(RQ * H_DIM);
+        w.q_rstd2 = c.f(RQ);
+        w.zq_cur = c.f(RQ * A);
+        w.zq_on = c.f(RQ * A);
+        w.zq_tg = c.f(RQ * A);
+        w.q_dq = c.f(RQ);
+        w.q_c1 = c.f(RQ);
+        w.q_c2 = c.f(RQ);
+        w.q_dpre1 = c.f(RQ * H_DIM);
+        w.q_Sb = w.q_Pb = w.q_Db = nullptr;
+        w.q_lossw = c.f(B);
+        w.q_uv = c.f(Hd * 2 * H_DIM);
+        w.q_kappa = c.f(2 * Q_MAX_HEADS);
+        w.q_wpk[0] = c.f(Hd * (size_t)H_DIM * E_DIM);
+        w.q_wpk[1] = c.f(d->has_target ? Hd * (size_t)H_DIM * E_DIM : 0);
+        w.de_q = c.f(Hd ? (size_t)B * E_DIM : 0);
+        w.q_slabs = c.f((size_t)N_CHUNKS * Hd * Q_SLAB);
+    }
     float *tb = c.f(3 * maxT * B);
     float *db = c.f(B);
     if (ws) *ws = w;
@@ -199,7 +230,6 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     return c.off;
 }
 
-static int post_blocks(int B) { return POST_SLAB_BLOCKS + (B + CONV_SPB - 1) / CONV_SPB + POST_SMALL_BLOCKS; }
 
 }  // namespace prism
 
@@ -219,7 +249,8 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(ld != nullptr, "null descriptor");
     if (iqn_supported(&ld->dims, ld->batch) != PRISM_OK) {
         set_error("prism_learner: model dims / batch not covered by the HIP kernels "
-                  "(need use_iqn, LN on, E=1024, K=64, H=128, T in {4,8,16,32,64}, B*T %% 16 == 0, no Q heads yet)");
+                  "(need LayerNorm on, E=1024; IQN: K=64, H=128, one trunk layer, T in {4,8,16,32,64}, B*T %% 16 == 0; "
+                  "Q heads: two layers of width 128, B %% 16 == 0)");
         return PRISM_ERR_UNSUPPORTED;
     }
     PRISM_CHECK_ARG(ld->params && ld->grads && ld->adam_m && ld->adam_v && ld->adam_step, "null parameter buffers");
@@ -229,7 +260,11 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(((uintptr_t)ld->workspace & 15) == 0, "workspace must be 16-byte aligned");
     PRISM_CHECK_ARG((((uintptr_t)ld->params | (uintptr_t)ld->grads | (uintptr_t)ld->adam_m | (uintptr_t)ld->adam_v) & 15) == 0,
                     "parameter / gradient / Adam buffers must be 16-byte aligned");
-    PRISM_CHECK_ARG(ld->off.n_params > 0 && (ld->off.phi_w & 3) == 0, "n_params / phi_w offset alignment");
+    PRISM_CHECK_ARG(ld->off.n_params > 0 && (!ld->dims.use_iqn || (ld->off.phi_w & 3) == 0),
+                    "n_params / phi_w offset alignment");
+    PRISM_CHECK_ARG(ld->dims.n_heads == 0 || (ld->off.head_base >= 0 && ld->off.h_w1 >= 0 && ld->off.h_w2 >= 0 &&
+                                              ld->off.h_ln1_g >= 0 && ld->off.h_ln2_g >= 0),
+                    "Q-head parameter offsets missing");
     PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
                     "null batch arrays");
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
@@ -253,6 +288,10 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.propagate_grad = d.propagate_grad;
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;
+    a.use_iqn = d.use_iqn;
+    a.n_heads = d.n_heads;
+    a.q_w = d.q_loss_weight;
+    a.theil_coef = d.n_heads > 1 ? d.theil_coef : 0.f;
     { const char *e = getenv("PRISM_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.stamps = (unsigned long long *)ld->dbg_stamps;
     if (!a.stamps) a.dbg &= ~8;
@@ -272,25 +311,40 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.tau_out = ld->tau_out ? ld->tau_out : tau_buf;
     a.maxT = d.n_tau > d.n_tau_next ? d.n_tau : d.n_tau_next;
     a.out_dl = ld->out_dist_loss ? ld->out_dist_loss : dl_buf;
+    a.out_ql = ld->out_q_loss ? ld->out_q_loss : dl_buf;
     a.out_td = ld->out_td;
     a.out_scalars = ld->out_scalars;
     a.grads = ld->grads;
     // passes, in the reference's tau draw order (iqn_model.py:104,112-126)
     int np = 0;
     const float *pk0 = a.ws.wpk[0], *pk1 = a.ws.wpk[1];
-    a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
-                           B * d.n_tau / 16, 1, 0};
-    if (!d.has_target || d.double_q) {
-        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_online, a.ws.zon,
-                               d.n_tau_next, B * d.n_tau_next / 16, 0, 1};
+    if (d.use_iqn) {
+        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
+                               B * d.n_tau / 16, 1, 0, 0};
+        if (!d.has_target || d.double_q) {
+            a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_online, a.ws.zon,
+                                   d.n_tau_next, B * d.n_tau_next / 16, 0, 1, 0};
+        }
+        if (d.has_target) {
+            a.pass[np++] = IqnPass{ld->target_params, pk1, pk1 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_target,
+                                   a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2, 0};
+        }
+        if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
+        else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
     }
-    if (d.has_target) {
-        a.pass[np++] = IqnPass{ld->target_params, pk1, pk1 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_target,
-                               a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2};
+    if (d.n_heads > 0) {
+        // Q-head tiles: (B/16) x heads per pass; same online/target selection (q_ensemble.py:62-68)
+        const int nt = (B / 16) * d.n_heads;
+        a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_cur, nullptr, a.ws.zq_cur, 1, nt, 1, 0, 1};
+        if (!d.has_target || d.double_q)
+            a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_next, nullptr, a.ws.zq_on, 1, nt, 0, 1, 1};
+        if (d.has_target)
+            a.pass[np++] = IqnPass{ld->target_params, nullptr, a.ws.q_wpk[1], a.ws.e_next, nullptr, a.ws.zq_tg, 1, nt, 0, 2,
+                                   1};
+        if (!d.has_target) a.ws.zq_tg = a.ws.zq_on;
+        else if (!d.double_q) a.ws.zq_on = a.ws.zq_tg;
     }
     a.n_pass = np;
-    if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
-    else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
 }
 
 static void fill_adam_args(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a) {
@@ -338,12 +392,19 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
             set_error("hipFuncSetAttribute(tile_fwd, %zu): %s", fwd_lds, hipGetErrorString(e));
             return PRISM_ERR_HIP;
         }
+        e = hipFuncSetAttribute((const void *)qh_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(QB_LDS_FLOATS * sizeof(float)));
+        if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute(qh_bwd): %s", hipGetErrorString(e));
+            return PRISM_ERR_HIP;
+        }
         attr_set = true;
     }
     if (!ld->embed_done) {
         ProfileScope ps_(K_EMBED, stream);
-        hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + H_DIM / 4 + PACK_BLOCKS * (1 + (ld->dims.has_target ? 1 : 0))), dim3(256), 0,
-                           stream, a);
+        hipLaunchKernelGGL(iqn_embed_kernel,
+                           dim3(2 * B + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target)), dim3(256),
+                           0, stream, a);
         PRISM_CHECK_LAUNCH();
     }
     {
@@ -351,19 +412,34 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
         PRISM_CHECK_LAUNCH();
     }
-    {
-        ProfileScope ps_(K_LOSS, stream);
-        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
-        PRISM_CHECK_LAUNCH();
+    if (ld->dims.use_iqn) {
+        {
+            ProfileScope ps_(K_LOSS, stream);
+            hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
+            PRISM_CHECK_LAUNCH();
+        }
+        {
+            ProfileScope ps_(K_BWD, stream);
+            hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+            PRISM_CHECK_LAUNCH();
+        }
     }
-    {
-        ProfileScope ps_(K_BWD, stream);
-        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
-        PRISM_CHECK_LAUNCH();
+    if (ld->dims.n_heads > 0) {
+        {
+            ProfileScope ps_(K_Q_FWD, stream);
+            hipLaunchKernelGGL(qh_loss_kernel, dim3(B), dim3(512), 0, stream, a);
+            PRISM_CHECK_LAUNCH();
+        }
+        {
+            ProfileScope ps_(K_Q_BWD, stream);
+            hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
+                               a);
+            PRISM_CHECK_LAUNCH();
+        }
     }
     {
         ProfileScope ps_(K_POST, stream);
-        hipLaunchKernelGGL(iqn_post_kernel, dim3(post_blocks(B)), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(iqn_post_kernel, dim3(post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads)), dim3(1024), 0, stream, a);
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dbg_z) {
@@ -377,7 +453,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
 // grid-norm partial slots valid for the Adam kernels: either what post left, or a fresh pass
 static int prepare_norm(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a, hipStream_t stream) {
     if (ld->hyper.grad_scale == 1.0f) {
-        a.n_slots = post_blocks(ld->batch);   // single replica: reuse the partials of the post kernel
+        a.n_slots = post_blocks(ld->batch, ld->dims.use_iqn, ld->dims.n_heads);   // single replica: reuse the post kernel's partials
     } else {
         // data parallel: the gradient was all-reduced after the backward; recompute the partials
         const int nb = 256;
@@ -445,7 +521,8 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     f.action = const_cast<int64_t *>(ld->action);
     {
         ProfileScope ps_(K_FRONT, stream);
-        hipLaunchKernelGGL(step_front_kernel, dim3(ld->batch + H_DIM / 4 + PACK_BLOCKS * (1 + (ld->dims.has_target ? 1 : 0))),
+        hipLaunchKernelGGL(step_front_kernel,
+                           dim3(ld->batch + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target)),
                            dim3(256), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }

@@ -1,0 +1,426 @@
+// Q-ensemble (IDS) / 2-layer DQN heads: loss, backward and the block routines of their gradient
+// reduction.  Restates /root/reference/prism/agents/models/q_ensemble.py:44-92 for heads of the form
+//   LayerNorm(1024) -> Linear(1024 -> 128) -> ReLU -> LayerNorm(128) -> Linear(128 -> A)
+// (ffnn_model.py:61-76 with n_layers = 2).  The forward of a head tile is kind 1 of iqn_tile_fwd_kernel.
+// Rows of all per-head workspace arrays are indexed  head * B + sample.
+#pragma once
+#include "iqn_kernels.h"
+
+namespace prism {
+
+constexpr int Q_SLAB = 2 * E_DIM + H_DIM * E_DIM;       // per head: ln1_g | ln1_b | w1
+constexpr int Q_MAX_HEADS = 16;
+
+// Head tensors start at arbitrary float offsets of the flat parameter buffer (head stride 134 278
+// floats), so they are only 4-byte aligned: no 16-byte accesses on them.
+__device__ __forceinline__ float4 ld4u(const float *p) { return float4{p[0], p[1], p[2], p[3]}; }
+
+// ---- front-kernel roles -------------------------------------------------------------------------
+// packed W1 of head `hd` (same fragment order as the IQN trunk weight)
+__device__ __forceinline__ void pack_head_w1_block(const float *__restrict__ P, const prism_param_offsets &off,
+                                                   float *__restrict__ pk, int hd, int blk, int tid) {
+    const int r = blk * 256 + tid;               // packed float4 index within the head, < H*E/4
+    const int lane = r & 63, li = lane & 15, g = lane >> 4;
+    const int q = (r >> 6) & 7, nt = (r >> 9) & 7, w = r >> 12;
+    const float *src = P + off.head_base + (int64_t)hd * off.head_stride + off.h_w1 +
+                       (int64_t)(16 * nt + li) * E_DIM + 128 * w + 16 * q + 4 * g;
+    reinterpret_cast<float4 *>(pk + (size_t)hd * H_DIM * E_DIM)[r] = ld4u(src);
+}
+constexpr int Q_PACK_BLOCKS_PER_HEAD = H_DIM * E_DIM / 4 / 256;   // 128
+
+// u_h[hh] = sum_n W1_h[hh][n] g1_h[n],  v_h[hh] = sum_n W1_h[hh][n] beta1_h[n]   (one wave per (head, hh))
+__device__ __forceinline__ void q_uv_block(const IqnArgs &a, int hd, int hh, int lane) {
+    const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    const float *W1 = Ph + a.off.h_w1 + (int64_t)hh * E_DIM, *g1 = Ph + a.off.h_ln1_g, *b1 = Ph + a.off.h_ln1_b;
+    float su = 0.f, sv = 0.f;
+#pragma unroll
+    for (int n = lane; n < E_DIM; n += 64) {
+        const float wv = W1[n];
+        su += wv * g1[n];
+        sv += wv * b1[n];
+    }
+    su = wave_sum(su);
+    sv = wave_sum(sv);
+    if (lane == 0) {
+        a.ws.q_uv[(hd * 2 + 0) * H_DIM + hh] = su;
+        a.ws.q_uv[(hd * 2 + 1) * H_DIM + hh] = sv;
+    }
+}
+
+// ||theta_h||^2 of one head (256 threads) -> q_kappa[Q_MAX_HEADS + hd]
+__device__ __forceinline__ void q_head_norm_block(const IqnArgs &a, int hd, float *s_red) {
+    const int tid = threadIdx.x;
+    const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    float s = 0.f;
+    for (int64_t i = tid; i < a.off.head_stride; i += 256) {
+        const float x = Ph[i];
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) s_red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) a.ws.q_kappa[Q_MAX_HEADS + hd] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Theil index of the head norms and its gradient factors (q_ensemble.py:86-90):
+//   r_h = n_h / mean(n), theil = mean(r log r);  d theil / d theta_{h,i} = c_h * theta_{h,i}
+__device__ __forceinline__ void theil_factors(const float *norm2, int Hd, float *c_out, float &theil) {
+    float n[Q_MAX_HEADS];
+    float m = 0.f;
+    for (int h = 0; h < Hd; ++h) {
+        n[h] = sqrtf(norm2[h]);
+        m += n[h];
+    }
+    m /= (float)Hd;
+    float t = 0.f, mix = 0.f;
+    for (int h = 0; h < Hd; ++h) {
+        const float r = n[h] / m;
+        t += r * logf(r);
+        mix += (logf(r) + 1.0f) * r;
+    }
+    theil = t / (float)Hd;
+    mix /= (float)Hd;
+    for (int h = 0; h < Hd; ++h) {
+        const float r = n[h] / m;
+        c_out[h] = ((logf(r) + 1.0f) - mix) / ((float)Hd * m * n[h]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// q loss: one workgroup (8 waves) per sample.  MSE against the n-step target per head, then the
+// head + LayerNorm(128) backward of the sample's row in every head.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
+    __shared__ float s_zc[Q_MAX_HEADS * 16], s_zo[Q_MAX_HEADS * 16], s_zt[Q_MAX_HEADS * 16];
+    __shared__ float s_dq[Q_MAX_HEADS], s_sq[Q_MAX_HEADS];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = a.B, A = a.A, Hd = a.n_heads;
+    // saved activations of this wave's rows (heads w, w + 8): in flight before the loss is known
+    float xa[2], xb[2], pa[2], pb[2], rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hd = w + 8 * i;
+        if (hd < Hd) {
+            const int64_t r = (int64_t)hd * B + b;
+            xa[i] = a.ws.q_xhat2[r * H_DIM + lane];
+            xb[i] = a.ws.q_xhat2[r * H_DIM + 64 + lane];
+            pa[i] = a.ws.q_pre1[r * H_DIM + lane];
+            pb[i] = a.ws.q_pre1[r * H_DIM + 64 + lane];
+            rs[i] = a.ws.q_rstd2[r];
+        }
+    }
+    const int act = (int)a.action[b];
+    for (int i = tid; i < Hd * A; i += 512) {
+        const int hd = i / A, aa = i - hd * A;
+        const int64_t o = ((int64_t)hd * B + b) * A + aa;
+        s_zc[i] = a.ws.zq_cur[o];
+        s_zo[i] = a.ws.zq_on[o];
+        s_zt[i] = a.ws.zq_tg[o];
+    }
+    __syncthreads();
+    const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+    if (tid < Hd) {
+        // a*_{b,h} = argmax_a Qon_next[b,a,h] (first maximum); y = R + Qtg_next[b,a*,h] * gamma*nonterminal
+        int best = 0;
+        float bv = s_zo[tid * A];
+        for (int aa = 1; aa < A; ++aa) {
+            const float v = s_zo[tid * A + aa];
+            if (v > bv) {
+                bv = v;
+                best = aa;
+            }
+        }
+        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+        const float y = a.reward[b] + s_zt[tid * A + best] * dg;
+        const float diff = s_zc[tid * A + act] - y;
+        s_sq[tid] = diff * diff;
+        s_dq[tid] = (wb / (float)B) * a.q_w * (2.0f / (float)Hd) * diff;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int h = 0; h < Hd; ++h) s += s_sq[h];
+        s = s / (float)Hd;
+        float theil = 0.f;
+        if (a.theil_coef != 0.f) {
+            float c[Q_MAX_HEADS];
+            theil_factors(a.ws.q_kappa + Q_MAX_HEADS, Hd, c, theil);
+        }
+        const float ql = a.q_w * (s - theil * a.theil_coef);
+        a.out_ql[b] = ql;
+        a.ws.q_lossw[b] = ql * wb;
+        // td errors (composite_model.py:135-142)
+        a.out_td[b] = a.use_iqn ? (a.out_dl[b] * 0.5f + ql * 0.5f) : fabsf(ql);
+        if (b == 0) a.out_scalars[4] = theil;
+    }
+    // head + LayerNorm(128) backward of row (head, b)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hd = w + 8 * i;
+        if (hd < Hd) {
+            const int64_t r = (int64_t)hd * B + b;
+            const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+            const float *W2 = Ph + a.off.h_w2 + (int64_t)act * H_DIM, *g2 = Ph + a.off.h_ln2_g, *b1 = Ph + a.off.h_b1;
+            const float *uv = a.ws.q_uv + (size_t)hd * 2 * H_DIM;
+            const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];
+            const float ua = uv[lane], ub = uv[lane + 64];
+            const float va = uv[H_DIM + lane] + b1[lane], vb = uv[H_DIM + lane + 64] + b1[lane + 64];
+            const float dq = s_dq[hd];
+            const float da = dq * w2a, db = dq * w2b;
+            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
+            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
+            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
+            ga = pa[i] > 0.f ? ga : 0.f;
+            gb = pb[i] > 0.f ? gb : 0.f;
+            a.ws.q_dpre1[r * H_DIM + lane] = ga;
+            a.ws.q_dpre1[r * H_DIM + 64 + lane] = gb;
+            const float c1 = wave_sum(ga * ua + gb * ub);
+            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+            if (lane == 0) {
+                a.ws.q_c1[r] = c1;
+                a.ws.q_c2[r] = c2;
+                a.ws.q_dq[r] = dq;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// q bwd: grid = (E/16 column slices) x n_chunks row chunks, 256 threads = 4 waves.  Heads outer, the
+// wave's sample tiles inner.  Per head: dX = dpre1 . W1 (columns of the slice), LayerNorm(1024)
+// backward with the saved row stats, dW1 / dLN slabs; the embedding gradient de[b][n] is accumulated
+// over heads in a per-wave LDS tile, so there is no cross-workgroup reduction at all.
+// ------------------------------------------------------------------------------------------
+constexpr int QB_MAX_TILES = 8;          // sample tiles per wave (B <= 4 * n_chunks * 16 * 8)
+constexpr int QB_ACC = 32 + 2;           // accumulators folded across the four waves
+constexpr int QB_STAGE = QB_ACC * 64;    // per-wave staging floats: dpre1 tile (16*HS = 2112) aliased with the fold buffer
+constexpr int QB_LDS_FLOATS = 4 * QB_STAGE + 4 * QB_MAX_TILES * 256;
+
+__global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const int cs = blockIdx.x % (E_DIM / 16), rc = blockIdx.x / (E_DIM / 16);
+    const int n = cs * 16 + j;
+    const int B = a.B, Hd = a.n_heads;
+    const int tiles_total = B / 16;
+    const int gw = rc * 4 + w, nw = a.n_chunks * 4;
+    const int tile_begin = (int)(((int64_t)tiles_total * gw) / nw);
+    const int n_tiles = (int)(((int64_t)tiles_total * (gw + 1)) / nw) - tile_begin;
+    float *dpl = smem + w * QB_STAGE;
+    float *deacc = smem + 4 * QB_STAGE + w * QB_MAX_TILES * 256;
+    float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area between barriers
+    for (int i = lane; i < QB_MAX_TILES * 256; i += 64) deacc[i] = 0.f;
+
+    for (int hd = 0; hd < Hd; ++hd) {
+        const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+        float w1f[32];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n]
+        {
+            const float *src = Ph + a.off.h_w1 + n;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) w1f[q * 4 + jj] = src[(int64_t)(16 * q + 4 * g + jj) * E_DIM];
+        }
+        const float g1 = Ph[a.off.h_ln1_g + n], be1 = Ph[a.off.h_ln1_b + n];
+        f32x4 accW1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float s_dg = 0.f, s_db = 0.f;
+        for (int ti = 0; ti < n_tiles; ++ti) {
+            const int b0 = (tile_begin + ti) * 16;
+            const int64_t row0 = (int64_t)hd * B + b0;
+            float4 ad[8];
+            const float *sd = a.ws.q_dpre1 + (row0 + j) * H_DIM + 4 * g;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
+            const int64_t rb = row0 + 4 * g;
+            const float4 mu = *reinterpret_cast<const float4 *>(a.ws.q_mu1 + rb);
+            const float4 rs = *reinterpret_cast<const float4 *>(a.ws.q_rstd1 + rb);
+            const float4 c1 = *reinterpret_cast<const float4 *>(a.ws.q_c1 + rb);
+            const float4 c2 = *reinterpret_cast<const float4 *>(a.ws.q_c2 + rb);
+            float ev[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ev[r] = a.ws.e_cur[(int64_t)(b0 + 4 * g + r) * E_DIM + n];
+            f32x4 adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                adx = mfma16(ad[2 * q].x, w1f[8 * q + 0], adx);
+                adx2 = mfma16(ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
+                adx = mfma16(ad[2 * q].y, w1f[8 * q + 1], adx);
+                adx2 = mfma16(ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
+                adx = mfma16(ad[2 * q].z, w1f[8 * q + 2], adx);
+                adx2 = mfma16(ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
+                adx = mfma16(ad[2 * q].w, w1f[8 * q + 3], adx);
+                adx2 = mfma16(ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
+            }
+            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+            const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
+            float xv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xhat = (ev[r] - muv[r]) * rsv[r];
+                xv[r] = xhat * g1 + be1;
+                const float dX = adx[r] + adx2[r];
+                s_dg += dX * xhat;
+                s_db += dX;
+                const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
+                deacc[ti * 256 + (4 * g + r) * 16 + j] += dh0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+                    accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
+            }
+        }
+        // fold the four waves in fixed order and write this head's part of the chunk slab
+        __syncthreads();
+        {
+            float *mine = red + (w * QB_ACC) * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(mt * 4 + r) * 64] = accW1[mt][r];
+            s_dg += __shfl_xor(s_dg, 16, 64);
+            s_dg += __shfl_xor(s_dg, 32, 64);
+            s_db += __shfl_xor(s_db, 16, 64);
+            s_db += __shfl_xor(s_db, 32, 64);
+            mine[32 * 64] = s_dg;
+            mine[33 * 64] = s_db;
+        }
+        __syncthreads();
+        float *slab = a.ws.q_slabs + ((int64_t)rc * Hd + hd) * Q_SLAB;
+        for (int idx = tid; idx < QB_ACC * 64; idx += 256) {
+            const int slot = idx >> 6, l = idx & 63;
+            const float v = ((red[(0 * QB_ACC + slot) * 64 + l] + red[(1 * QB_ACC + slot) * 64 + l]) +
+                             red[(2 * QB_ACC + slot) * 64 + l]) + red[(3 * QB_ACC + slot) * 64 + l];
+            const int lj = l & 15, lg = l >> 4;
+            if (slot < 32) {
+                const int mt = slot >> 2, r = slot & 3;        // row hh = 16*mt + 4*lg + r, col n = cs*16 + lj
+                slab[2 * E_DIM + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
+            } else if (lg == 0) {
+                if (slot == 32) slab[cs * 16 + lj] = v;            // d ln1_g
+                else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
+            }
+        }
+        __syncthreads();
+    }
+    // embedding gradient of this wave's samples, summed over heads
+    for (int ti = 0; ti < n_tiles; ++ti) {
+        const int b0 = (tile_begin + ti) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a.ws.de_q[(int64_t)(b0 + 4 * g + r) * E_DIM + n] = deacc[ti * 256 + (4 * g + r) * 16 + j];
+    }
+}
+
+// ---- post-kernel roles ---------------------------------------------------------------------------
+// slab sum of the Q heads: float4 index i over [heads][Q_SLAB/4]; adds the Theil term kappa_h * theta
+__device__ __forceinline__ void q_slab_sum(const IqnArgs &a, int64_t i, const float *kappa, float &sq) {
+    const int per_head = Q_SLAB / 4;
+    const int hd = (int)(i / per_head);
+    const int64_t o = (i - (int64_t)hd * per_head) * 4;
+    float4 s = *reinterpret_cast<const float4 *>(a.ws.q_slabs + (int64_t)hd * Q_SLAB + o);
+    float4 v[7];
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (c < a.n_chunks) v[c - 1] = *reinterpret_cast<const float4 *>(a.ws.q_slabs + ((int64_t)c * a.n_heads + hd) * Q_SLAB + o);
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+        if (c < a.n_chunks) {
+            s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
+        }
+    // parameter order inside a head: ln1_g | ln1_b | w1 (contiguous), the slab has the same order
+    const int64_t po = a.off.head_base + (int64_t)hd * a.off.head_stride + a.off.h_ln1_g + o;
+    if (kappa) {
+        const float4 th = ld4u(a.params + po);
+        const float k = kappa[hd];
+        s.x += k * th.x; s.y += k * th.y; s.z += k * th.z; s.w += k * th.w;
+    }
+    float *gp = a.grads + po;
+    gp[0] = s.x; gp[1] = s.y; gp[2] = s.z; gp[3] = s.w;
+    sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+}
+
+// b1, LN2 affine, W2, b2 gradients of head `hd` for the 64 hidden units [slice*64, +64).  1024 threads.
+__device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, int slice, const float *kappa, float &sq) {
+    __shared__ float s_part[16][64];
+    __shared__ float s_S[16][64];
+    __shared__ float s_D[16];
+    const int tid = threadIdx.x, B = a.B, A = a.A;
+    const int hl = tid & 63, part = tid >> 6, h = slice * 64 + hl;
+    const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    float *Gh = a.grads + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    float sA[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
+    float pb = 0.f;
+#pragma unroll 4
+    for (int b = part; b < B; b += 16) {
+        const int64_t r = (int64_t)hd * B + b;
+        const float v = a.ws.q_dq[r] * a.ws.q_xhat2[r * H_DIM + h];
+        pb += a.ws.q_dpre1[r * H_DIM + h];
+        const int ab = (int)a.action[b];
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
+    }
+    {
+        float s = 0.f;
+        if (part < A)
+            for (int b = hl; b < B; b += 64) s += ((int)a.action[b] == part) ? a.ws.q_dq[(int64_t)hd * B + b] : 0.f;
+        s = wave_sum(s);
+        if (hl == 0) s_D[part] = s;
+    }
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) {
+        if (aa < A) {
+            __syncthreads();
+            s_part[part][hl] = sA[aa];
+            __syncthreads();
+            if (part == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+                s_S[aa][hl] = t;
+            }
+        }
+    }
+    __syncthreads();
+    s_part[part][hl] = pb;
+    __syncthreads();
+    const float k = kappa ? kappa[hd] : 0.f;
+    if (part == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+        t += k * Ph[a.off.h_b1 + h];
+        Gh[a.off.h_b1 + h] = t;
+        sq += t * t;
+        const float g2 = Ph[a.off.h_ln2_g + h], be2 = Ph[a.off.h_ln2_b + h];
+        float dg = 0.f, db = 0.f;
+        for (int aa = 0; aa < A; ++aa) {
+            const float w2 = Ph[a.off.h_w2 + aa * H_DIM + h];
+            const float S = s_S[aa][hl], D = s_D[aa];
+            const float dw = g2 * S + be2 * D + k * w2;
+            Gh[a.off.h_w2 + aa * H_DIM + h] = dw;
+            sq += dw * dw;
+            dg += w2 * S;
+            db += w2 * D;
+        }
+        dg += k * g2;
+        db += k * be2;
+        Gh[a.off.h_ln2_g + h] = dg;
+        Gh[a.off.h_ln2_b + h] = db;
+        sq += dg * dg + db * db;
+    }
+    if (slice == 0 && tid < A) {
+        const float D = s_D[tid] + k * Ph[a.off.h_b2 + tid];
+        Gh[a.off.h_b2 + tid] = D;
+        sq += D * D;
+    }
+}
+
+}  // namespace prism

@@ -5,9 +5,66 @@
 // replay_kernels.h, so fused and unfused paths execute the same arithmetic.
 #pragma once
 #include "iqn_kernels.h"
+#include "qhead_kernels.h"
 #include "replay_kernels.h"
 
 namespace prism {
+
+
+// ---- the parameter-only roles that ride along with the embed / front launch ---------------------
+// IQN: u,v (H/4 blocks), weight packing (PACK_BLOCKS, x2 with a target network);
+// Q heads: per head W1 packing (x2 with target), u_h,v_h (H/4 blocks), ||theta_h||^2 (1 block).
+__host__ __device__ inline int front_extra_blocks(int use_iqn, int n_heads, int has_target) {
+    int n = 0;
+    if (use_iqn) n += H_DIM / 4 + PACK_BLOCKS * (1 + (has_target ? 1 : 0));
+    n += n_heads * (Q_PACK_BLOCKS_PER_HEAD * (1 + (has_target ? 1 : 0)) + H_DIM / 4 + 1);
+    return n;
+}
+
+__device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float *s_red) {
+    const int tid = threadIdx.x;
+    if (a.use_iqn) {
+        if (x < H_DIM / 4) {
+            iqn_uv_block(a, x * 4 + (tid >> 6), tid & 63);
+            return;
+        }
+        x -= H_DIM / 4;
+        if (x < PACK_BLOCKS) {
+            pack_weights_block(a.params, a.off, a.ws.wpk[0], x, tid);
+            return;
+        }
+        x -= PACK_BLOCKS;
+        if (a.has_target) {
+            if (x < PACK_BLOCKS) {
+                pack_weights_block(a.target_params, a.off, a.ws.wpk[1], x, tid);
+                return;
+            }
+            x -= PACK_BLOCKS;
+        }
+    }
+    const int per_head = Q_PACK_BLOCKS_PER_HEAD * (1 + (a.has_target ? 1 : 0)) + H_DIM / 4 + 1;
+    const int hd = x / per_head;
+    x -= hd * per_head;
+    if (x < Q_PACK_BLOCKS_PER_HEAD) {
+        pack_head_w1_block(a.params, a.off, a.ws.q_wpk[0], hd, x, tid);
+        return;
+    }
+    x -= Q_PACK_BLOCKS_PER_HEAD;
+    if (a.has_target) {
+        if (x < Q_PACK_BLOCKS_PER_HEAD) {
+            pack_head_w1_block(a.target_params, a.off, a.ws.q_wpk[1], hd, x, tid);
+            return;
+        }
+        x -= Q_PACK_BLOCKS_PER_HEAD;
+    }
+    if (x < H_DIM / 4) {
+        q_uv_block(a, hd, x * 4 + (tid >> 6), tid & 63);
+        return;
+    }
+    q_head_norm_block(a, hd, s_red);
+}
+
+__device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red) { front_extra_block(a, x, s_red); }
 
 struct FrontArgs {
     int64_t size;          // stored items
@@ -37,14 +94,8 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     __shared__ uint32_t s_flags;
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
-    if (b >= B + H_DIM / 4) {
-        const int pb = b - (B + H_DIM / 4);
-        if (pb < PACK_BLOCKS) pack_weights_block(a.params, a.off, a.ws.wpk[0], pb, tid);
-        else pack_weights_block(a.target_params, a.off, a.ws.wpk[1], pb - PACK_BLOCKS, tid);
-        return;
-    }
     if (b >= B) {
-        iqn_uv_block(a, (b - B) * 4 + (tid >> 6), tid & 63);
+        front_extra_block(a, b - B, s_scratch);
         return;
     }
     // conv weights of both networks: independent of everything else, get them in flight first
@@ -137,6 +188,14 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
 constexpr int POST_SLAB_BLOCKS = (SLAB / 4 + 1023) / 1024;   // 49
 constexpr int POST_SMALL_BLOCKS = H_DIM / 64;                // 2
 
+__host__ __device__ inline int post_q_slab_blocks(int n_heads) { return (n_heads * (Q_SLAB / 4) + 1023) / 1024; }
+__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads) {
+    int n = (B + CONV_SPB - 1) / CONV_SPB;
+    if (use_iqn) n += POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
+    if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_SMALL_BLOCKS;
+    return n;
+}
+
 __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     const int tid = threadIdx.x;
     v = wave_sum(v);
@@ -154,32 +213,16 @@ __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
 
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
     __shared__ float s_red[64];
+    __shared__ float s_kappa[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const int n_conv = (B + CONV_SPB - 1) / CONV_SPB;
-    const int blk = blockIdx.x;
+    int blk = blockIdx.x;
     float sq = 0.f;
-    if (blk < POST_SLAB_BLOCKS) {
-        const int i = blk * 1024 + tid;
-        if (i < SLAB / 4) {
-            float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
-            float4 v[7];
-#pragma unroll
-            for (int c = 1; c < 8; ++c)
-                if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * SLAB)[i];
-#pragma unroll
-            for (int c = 1; c < 8; ++c)
-                if (c < a.n_chunks) {
-                    s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
-                }
-            *reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i) = s;
-            sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
-        }
-    } else if (blk < POST_SLAB_BLOCKS + n_conv) {
+    if (blk < n_conv) {
         __shared__ float s_obs[CONV_SPB][1000];
         __shared__ float s_dc[CONV_SPB][16 * 65];
         __shared__ int s_last;
-        const int cb = blk - POST_SLAB_BLOCKS;
-        conv_bwd_partial_block(a, cb, &s_obs[0][0], &s_dc[0][0]);
+        conv_bwd_partial_block(a, blk, &s_obs[0][0], &s_dc[0][0]);
         // publish, then let the last arriver fold all partial rows: ONE lane releases after the
         // block's stores have drained (the barrier waits for them), ONE lane acquires
         __syncthreads();
@@ -206,7 +249,77 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
             if (tid == 0) a.ws.ticket[1] = 0u;
         }
     } else {
-        small_tensor_block(a, blk - POST_SLAB_BLOCKS - n_conv, sq);
+        blk -= n_conv;
+        bool done = false;
+        if (a.use_iqn) {
+            if (blk < POST_SLAB_BLOCKS) {
+                const int i = blk * 1024 + tid;
+                if (i < SLAB / 4) {
+                    float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
+                    float4 v[7];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c)
+                        if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * SLAB)[i];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c)
+                        if (c < a.n_chunks) {
+                            s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
+                        }
+                    *reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i) = s;
+                    sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+                }
+                done = true;
+            } else if (blk < POST_SLAB_BLOCKS + POST_SMALL_BLOCKS) {
+                small_tensor_block(a, blk - POST_SLAB_BLOCKS, sq);
+                done = true;
+            } else {
+                blk -= POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
+            }
+        }
+        if (!done) {
+            // Q-head roles.  Theil gradient factor per head: dL/dtheta += kappa_h * theta with
+            // kappa_h = -q_w * coef * mean_b(w_b) * c_h   (q_ensemble.py:86-92, agent.py:62-64)
+            const float *kappa = nullptr;
+            if (a.theil_coef != 0.f) {
+                float mw = 0.f;
+                if (a.per_weights) {
+                    for (int b = tid; b < B; b += 1024) mw += a.per_weights[b];
+                } else if (tid == 0) {
+                    mw = (float)B;
+                }
+                const float tot = block_sum_1024(mw, s_red);
+                if (tid == 0) {
+                    float c[Q_MAX_HEADS], theil;
+                    theil_factors(a.ws.q_kappa + Q_MAX_HEADS, a.n_heads, c, theil);
+                    const float f = -a.q_w * a.theil_coef * (tot / (float)B);
+                    for (int h = 0; h < a.n_heads; ++h) s_kappa[h] = f * c[h];
+                }
+                __syncthreads();
+                kappa = s_kappa;
+            }
+            const int nqs = post_q_slab_blocks(a.n_heads);
+            if (blk < nqs) {
+                const int64_t i = (int64_t)blk * 1024 + tid;
+                if (i < (int64_t)a.n_heads * (Q_SLAB / 4)) q_slab_sum(a, i, kappa, sq);
+            } else {
+                const int x = blk - nqs;
+                q_small_tensor_block(a, x / POST_SMALL_BLOCKS, x % POST_SMALL_BLOCKS, kappa, sq);
+                if (x == 0) {
+                    // total loss (agent.py:58-64): mean(dl*w) [already in out_scalars[1]] + mean(ql*w)
+                    float lw = 0.f;
+                    for (int b = tid; b < B; b += 1024) lw += a.ws.q_lossw[b];
+                    const float tq = block_sum_1024(lw, s_red);
+                    if (tid == 0) {
+                        float ld = 0.f;
+                        if (a.use_iqn)
+                            for (int b = 0; b < B; ++b) ld += a.ws.lossw[b];
+                        ld /= (float)B;
+                        a.out_scalars[2] = tq / (float)B;
+                        a.out_scalars[0] = ld + tq / (float)B;
+                    }
+                }
+            }
+        }
     }
     const float t = block_sum_1024(sq, s_red);
     if (tid == 0) a.ws.normpart[blockIdx.x] = t;

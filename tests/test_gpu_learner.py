@@ -44,7 +44,8 @@ def to_hip_batch(batch, dev):
                   "action": batch["action"].view(B, 1).to(dev)}, B, dev)
 
 
-IQN_CASES = ["iqn_small", "iqn_c3", "iqn_tau32", "iqn_target", "iqn_doubleq"]
+IQN_CASES = ["iqn_small", "iqn_c3", "iqn_tau32", "iqn_target", "iqn_doubleq",
+             "full_small", "full_notarget", "full_doubleq", "full_c4"]
 
 
 @pytest.mark.parametrize("name", IQN_CASES)
@@ -69,6 +70,9 @@ def test_iqn_update_matches_reference_and_oracle(dev, name):
         np.testing.assert_allclose(td.cpu().numpy(), g[pre + "td"], rtol=0, atol=LOSS_TOL)
         np.testing.assert_allclose(agent._static_distribution_loss.cpu().numpy(), g[pre + "dl"], rtol=0,
                                    atol=LOSS_TOL)
+        if pre + "ql" in g.files:
+            np.testing.assert_allclose(agent._static_q_loss.cpu().numpy(), g[pre + "ql"], rtol=0, atol=LOSS_TOL)
+            assert abs(float(agent.scalars[4]) - float(g[pre + "theil"])) < 1e-6
         assert abs(float(agent._static_total_loss) - float(g[pre + "total"])) < LOSS_TOL
         np.testing.assert_allclose(td.cpu().numpy(), td_o.numpy(), rtol=0, atol=LOSS_TOL)
         # gradients vs oracle autograd (unclipped)
