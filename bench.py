@@ -41,12 +41,22 @@ def algorithmic_bytes(cfg, P, P_tgt, cap2_levels):
 
 
 def kernel_flops(cfg, B, A=6):
+    """Algorithmic flops per launch of the two GEMM kernels."""
     T, Tn, E, K, H = cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples, 1024, 64, 128
-    per_row_fwd = 2 * K * E + 2 * E * H + 2 * H * A
     n_next = 2 if (cfg.use_target_network and cfg.use_double_q_learning) else 1
-    rows_fwd = B * T + n_next * B * Tn
-    fl = {"iqn_tile_fwd_kernel": rows_fwd * per_row_fwd,
-          "iqn_bwd_kernel": B * T * 2 * E * (K + H + K + H)}
+    fwd = bwd = qbwd = 0
+    if cfg.use_iqn:
+        fwd += (B * T + n_next * B * Tn) * (2 * K * E + 2 * E * H + 2 * H * A)
+        bwd += B * T * 2 * E * (K + H + K + H)
+    heads = cfg.ids_n_q_heads if cfg.use_ids else (1 if cfg.use_dqn and cfg.dqn_n_model_layers == 2 else 0)
+    if heads:
+        fwd += (1 + n_next) * B * heads * (2 * E * H + 2 * H * A)
+        qbwd += B * heads * 2 * E * (H + H)
+    fl = {"iqn_tile_fwd_kernel": fwd}
+    if bwd:
+        fl["iqn_bwd_kernel"] = bwd
+    if qbwd:
+        fl["q_bwd_kernel"] = qbwd
     return fl
 
 

@@ -60,8 +60,8 @@ struct IqnWs {           // workspace pointers (device)
     float *q_uv;         // [heads][2][H]
     float *q_kappa;      // [heads] Theil gradient factors, [heads] = theil value
     float *q_wpk[2];     // [online, target] packed W1 of every head
-    float *de_q;         // [B][E] embedding gradient from the Q heads
-    float *q_slabs;      // [n_chunks][heads][Q_SLAB]
+    float *de_q;         // [heads][B][E] embedding gradient of each Q head
+    float *q_slabs;      // [heads][Q_SLAB]
     float *slabs;        // [n_chunks][SLAB]
     float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
     float *normpart;     // [NORM_SLOTS]
@@ -907,7 +907,7 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         const int s = i >> 10, n = i & 1023;
         const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
         float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
-        if (a.n_heads > 0) d += a.ws.de_q[o];
+        for (int hd = 0; hd < a.n_heads; ++hd) d += a.ws.de_q[(size_t)hd * B * E_DIM + o];   // heads in fixed order
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();

@@ -145,6 +145,8 @@ struct Carver {
     }
 };
 
+static constexpr int N_CHUNKS = BWD_CHUNKS;
+
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
@@ -158,14 +160,13 @@ static int iqn_supported(const prism_model_dims *d, int32_t B) {
         // ensemble / DQN heads of the form LN -> Linear(1024,128) -> ReLU -> LN -> Linear(128,A)
         if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || d->head_width != H_DIM)
             return PRISM_ERR_UNSUPPORTED;
-        if (B % 16 || B / 16 > 4 * BWD_CHUNKS * QB_MAX_TILES) return PRISM_ERR_UNSUPPORTED;
+        if (B % 16) return PRISM_ERR_UNSUPPORTED;
     }
     if (B < 1 || B > SMALL_MAX_B) return PRISM_ERR_UNSUPPORTED;
     if (d->n_actions < 1 || d->n_actions > 16 || d->in_channels < 1 || d->in_channels > 10) return PRISM_ERR_UNSUPPORTED;
     return PRISM_OK;
 }
 
-static constexpr int N_CHUNKS = BWD_CHUNKS;
 
 static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws, float **tau_buf, float **dl_buf) {
     Carver c(base);
@@ -216,11 +217,11 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_Sb = w.q_Pb = w.q_Db = nullptr;
         w.q_lossw = c.f(B);
         w.q_uv = c.f(Hd * 2 * H_DIM);
-        w.q_kappa = c.f(2 * Q_MAX_HEADS);
+        w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
         w.q_wpk[0] = c.f(Hd * (size_t)H_DIM * E_DIM);
         w.q_wpk[1] = c.f(d->has_target ? Hd * (size_t)H_DIM * E_DIM : 0);
-        w.de_q = c.f(Hd ? (size_t)B * E_DIM : 0);
-        w.q_slabs = c.f((size_t)N_CHUNKS * Hd * Q_SLAB);
+        w.de_q = c.f(Hd * (size_t)B * E_DIM);
+        w.q_slabs = c.f(Hd * (size_t)Q_SLAB);
     }
     float *tb = c.f(3 * maxT * B);
     float *db = c.f(B);
@@ -432,7 +433,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         }
         {
             ProfileScope ps_(K_Q_BWD, stream);
-            hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
+            hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * ld->dims.n_heads), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
                                a);
             PRISM_CHECK_LAUNCH();
         }

@@ -47,19 +47,23 @@ __device__ __forceinline__ void q_uv_block(const IqnArgs &a, int hd, int hh, int
     }
 }
 
-// ||theta_h||^2 of one head (256 threads) -> q_kappa[Q_MAX_HEADS + hd]
-__device__ __forceinline__ void q_head_norm_block(const IqnArgs &a, int hd, float *s_red) {
+// ||theta_h||^2 of one head, Q_NORM_PARTS blocks of 256 threads each -> q_kappa[(hd * Q_NORM_PARTS + part)]
+constexpr int Q_NORM_PARTS = 16;
+__device__ __forceinline__ void q_head_norm_block(const IqnArgs &a, int hd, int part, float *s_red) {
     const int tid = threadIdx.x;
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    const int64_t per = (a.off.head_stride + Q_NORM_PARTS - 1) / Q_NORM_PARTS;
+    const int64_t i0 = part * per, i1 = i0 + per < a.off.head_stride ? i0 + per : a.off.head_stride;
     float s = 0.f;
-    for (int64_t i = tid; i < a.off.head_stride; i += 256) {
+#pragma unroll 8
+    for (int64_t i = i0 + tid; i < i1; i += 256) {
         const float x = Ph[i];
         s += x * x;
     }
     s = wave_sum(s);
     if ((tid & 63) == 0) s_red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) a.ws.q_kappa[Q_MAX_HEADS + hd] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tid == 0) a.ws.q_kappa[hd * Q_NORM_PARTS + part] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // Theil index of the head norms and its gradient factors (q_ensemble.py:86-90):
@@ -85,6 +89,19 @@ __device__ __forceinline__ void theil_factors(const float *norm2, int Hd, float 
         c_out[h] = ((logf(r) + 1.0f) - mix) / ((float)Hd * m * n[h]);
     }
 }
+// all threads: gather the Q_NORM_PARTS partial sums of every head into s_norm2[Hd] (one parallel round
+// of loads instead of a serial chain in one lane); caller synchronises before reading
+__device__ __forceinline__ void stage_head_norms(const IqnArgs &a, float *s_parts, float *s_norm2) {
+    const int tid = threadIdx.x, n = a.n_heads * Q_NORM_PARTS;
+    if (tid < n) s_parts[tid] = a.ws.q_kappa[tid];
+    __syncthreads();
+    if (tid < a.n_heads) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < Q_NORM_PARTS; ++p) s += s_parts[tid * Q_NORM_PARTS + p];
+        s_norm2[tid] = s;
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // q loss: one workgroup (8 waves) per sample.  MSE against the n-step target per head, then the
@@ -93,6 +110,7 @@ __device__ __forceinline__ void theil_factors(const float *norm2, int Hd, float 
 __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
     __shared__ float s_zc[Q_MAX_HEADS * 16], s_zo[Q_MAX_HEADS * 16], s_zt[Q_MAX_HEADS * 16];
     __shared__ float s_dq[Q_MAX_HEADS], s_sq[Q_MAX_HEADS];
+    __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, Hd = a.n_heads;
     // saved activations of this wave's rows (heads w, w + 8): in flight before the loss is known
@@ -110,6 +128,7 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         }
     }
     const int act = (int)a.action[b];
+    if (a.theil_coef != 0.f) stage_head_norms(a, s_parts, s_norm2);
     for (int i = tid; i < Hd * A; i += 512) {
         const int hd = i / A, aa = i - hd * A;
         const int64_t o = ((int64_t)hd * B + b) * A + aa;
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         float theil = 0.f;
         if (a.theil_coef != 0.f) {
             float c[Q_MAX_HEADS];
-            theil_factors(a.ws.q_kappa + Q_MAX_HEADS, Hd, c, theil);
+            theil_factors(s_norm2, Hd, c, theil);
         }
         const float ql = a.q_w * (s - theil * a.theil_coef);
         a.out_ql[b] = ql;
@@ -186,134 +205,121 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// q bwd: grid = (E/16 column slices) x n_chunks row chunks, 256 threads = 4 waves.  Heads outer, the
-// wave's sample tiles inner.  Per head: dX = dpre1 . W1 (columns of the slice), LayerNorm(1024)
-// backward with the saved row stats, dW1 / dLN slabs; the embedding gradient de[b][n] is accumulated
-// over heads in a per-wave LDS tile, so there is no cross-workgroup reduction at all.
+// q bwd: grid = (E/16 column slices) x heads, 256 threads = 4 waves, each wave a strided set of the
+// B/16 sample tiles.  dX = dpre1 . W1 (columns of the slice), LayerNorm(1024) backward with the saved
+// row stats, dW1 / dLN written straight to this head's gradient slab (one slab: every workgroup owns
+// its (head, column slice) outright), embedding gradient per head -> de_q[head][b][n] (summed over
+// heads where it is consumed, conv_bwd_partial_block).
 // ------------------------------------------------------------------------------------------
-constexpr int QB_MAX_TILES = 8;          // sample tiles per wave (B <= 4 * n_chunks * 16 * 8)
 constexpr int QB_ACC = 32 + 2;           // accumulators folded across the four waves
 constexpr int QB_STAGE = QB_ACC * 64;    // per-wave staging floats: dpre1 tile (16*HS = 2112) aliased with the fold buffer
-constexpr int QB_LDS_FLOATS = 4 * QB_STAGE + 4 * QB_MAX_TILES * 256;
+constexpr int QB_LDS_FLOATS = 4 * QB_STAGE;
 
 __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int cs = blockIdx.x % (E_DIM / 16), rc = blockIdx.x / (E_DIM / 16);
+    const int cs = blockIdx.x % (E_DIM / 16), hd = blockIdx.x / (E_DIM / 16);
     const int n = cs * 16 + j;
-    const int B = a.B, Hd = a.n_heads;
+    const int B = a.B;
     const int tiles_total = B / 16;
-    const int gw = rc * 4 + w, nw = a.n_chunks * 4;
-    const int tile_begin = (int)(((int64_t)tiles_total * gw) / nw);
-    const int n_tiles = (int)(((int64_t)tiles_total * (gw + 1)) / nw) - tile_begin;
     float *dpl = smem + w * QB_STAGE;
-    float *deacc = smem + 4 * QB_STAGE + w * QB_MAX_TILES * 256;
-    float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area between barriers
-    for (int i = lane; i < QB_MAX_TILES * 256; i += 64) deacc[i] = 0.f;
-
-    for (int hd = 0; hd < Hd; ++hd) {
-        const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
-        float w1f[32];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n]
-        {
-            const float *src = Ph + a.off.h_w1 + n;
+    float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area after the barrier
+    const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    float w1f[32];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n], gathered from the fragment-packed copy:
+    {                 // each (q, jj) load stays inside one contiguous 1 KB block instead of striding 4 KB rows
+        const float *pk = a.ws.q_wpk[0] + (size_t)hd * H_DIM * E_DIM;
+        const int wv = n >> 7, qn = (n >> 4) & 7, gp = (n >> 2) & 3, jn = n & 3;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) w1f[q * 4 + jj] = src[(int64_t)(16 * q + 4 * g + jj) * E_DIM];
+            for (int jj = 0; jj < 4; ++jj)
+                w1f[q * 4 + jj] = pk[((((size_t)wv * 8 + q) * 8 + qn) * 64 + gp * 16 + 4 * g + jj) * 4 + jn];
+    }
+    const float g1 = Ph[a.off.h_ln1_g + n], be1 = Ph[a.off.h_ln1_b + n];
+    f32x4 accW1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s_dg = 0.f, s_db = 0.f;
+    float *de_h = a.ws.de_q + (size_t)hd * B * E_DIM;
+    for (int t = w; t < tiles_total; t += 4) {
+        const int b0 = t * 16;
+        const int64_t row0 = (int64_t)hd * B + b0;
+        float4 ad[8];
+        const float *sd = a.ws.q_dpre1 + (row0 + j) * H_DIM + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
+        const int64_t rb = row0 + 4 * g;
+        const float4 mu = *reinterpret_cast<const float4 *>(a.ws.q_mu1 + rb);
+        const float4 rs = *reinterpret_cast<const float4 *>(a.ws.q_rstd1 + rb);
+        const float4 c1 = *reinterpret_cast<const float4 *>(a.ws.q_c1 + rb);
+        const float4 c2 = *reinterpret_cast<const float4 *>(a.ws.q_c2 + rb);
+        float ev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[r] = a.ws.e_cur[(int64_t)(b0 + 4 * g + r) * E_DIM + n];
+        f32x4 adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            adx = mfma16(ad[2 * q].x, w1f[8 * q + 0], adx);
+            adx2 = mfma16(ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
+            adx = mfma16(ad[2 * q].y, w1f[8 * q + 1], adx);
+            adx2 = mfma16(ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
+            adx = mfma16(ad[2 * q].z, w1f[8 * q + 2], adx);
+            adx2 = mfma16(ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
+            adx = mfma16(ad[2 * q].w, w1f[8 * q + 3], adx);
+            adx2 = mfma16(ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
         }
-        const float g1 = Ph[a.off.h_ln1_g + n], be1 = Ph[a.off.h_ln1_b + n];
-        f32x4 accW1[8];
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+        const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
+        float xv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float s_dg = 0.f, s_db = 0.f;
-        for (int ti = 0; ti < n_tiles; ++ti) {
-            const int b0 = (tile_begin + ti) * 16;
-            const int64_t row0 = (int64_t)hd * B + b0;
-            float4 ad[8];
-            const float *sd = a.ws.q_dpre1 + (row0 + j) * H_DIM + 4 * g;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
-            const int64_t rb = row0 + 4 * g;
-            const float4 mu = *reinterpret_cast<const float4 *>(a.ws.q_mu1 + rb);
-            const float4 rs = *reinterpret_cast<const float4 *>(a.ws.q_rstd1 + rb);
-            const float4 c1 = *reinterpret_cast<const float4 *>(a.ws.q_c1 + rb);
-            const float4 c2 = *reinterpret_cast<const float4 *>(a.ws.q_c2 + rb);
-            float ev[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ev[r] = a.ws.e_cur[(int64_t)(b0 + 4 * g + r) * E_DIM + n];
-            f32x4 adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                adx = mfma16(ad[2 * q].x, w1f[8 * q + 0], adx);
-                adx2 = mfma16(ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
-                adx = mfma16(ad[2 * q].y, w1f[8 * q + 1], adx);
-                adx2 = mfma16(ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
-                adx = mfma16(ad[2 * q].z, w1f[8 * q + 2], adx);
-                adx2 = mfma16(ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
-                adx = mfma16(ad[2 * q].w, w1f[8 * q + 3], adx);
-                adx2 = mfma16(ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
-            }
-            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-            const float c1v[4] = {c1.x, c1.y, c1.z, c1.w}, c2v[4] = {c2.x, c2.y, c2.z, c2.w};
-            float xv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float xhat = (ev[r] - muv[r]) * rsv[r];
-                xv[r] = xhat * g1 + be1;
-                const float dX = adx[r] + adx2[r];
-                s_dg += dX * xhat;
-                s_db += dX;
-                const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
-                deacc[ti * 256 + (4 * g + r) * 16 + j] += dh0;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt)
-                    accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const float xhat = (ev[r] - muv[r]) * rsv[r];
+            xv[r] = xhat * g1 + be1;
+            const float dX = adx[r] + adx2[r];
+            s_dg += dX * xhat;
+            s_db += dX;
+            const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
+            de_h[(int64_t)(b0 + 4 * g + r) * E_DIM + n] = dh0;
         }
-        // fold the four waves in fixed order and write this head's part of the chunk slab
-        __syncthreads();
-        {
-            float *mine = red + (w * QB_ACC) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(mt * 4 + r) * 64] = accW1[mt][r];
-            s_dg += __shfl_xor(s_dg, 16, 64);
-            s_dg += __shfl_xor(s_dg, 32, 64);
-            s_db += __shfl_xor(s_db, 16, 64);
-            s_db += __shfl_xor(s_db, 32, 64);
-            mine[32 * 64] = s_dg;
-            mine[33 * 64] = s_db;
+                accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
         }
-        __syncthreads();
-        float *slab = a.ws.q_slabs + ((int64_t)rc * Hd + hd) * Q_SLAB;
-        for (int idx = tid; idx < QB_ACC * 64; idx += 256) {
-            const int slot = idx >> 6, l = idx & 63;
-            const float v = ((red[(0 * QB_ACC + slot) * 64 + l] + red[(1 * QB_ACC + slot) * 64 + l]) +
-                             red[(2 * QB_ACC + slot) * 64 + l]) + red[(3 * QB_ACC + slot) * 64 + l];
-            const int lj = l & 15, lg = l >> 4;
-            if (slot < 32) {
-                const int mt = slot >> 2, r = slot & 3;        // row hh = 16*mt + 4*lg + r, col n = cs*16 + lj
-                slab[2 * E_DIM + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
-            } else if (lg == 0) {
-                if (slot == 32) slab[cs * 16 + lj] = v;            // d ln1_g
-                else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
-            }
-        }
-        __syncthreads();
     }
-    // embedding gradient of this wave's samples, summed over heads
-    for (int ti = 0; ti < n_tiles; ++ti) {
-        const int b0 = (tile_begin + ti) * 16;
+    // fold the four waves in fixed order and write this head's slab slice
+    __syncthreads();
+    {
+        float *mine = red + (w * QB_ACC) * 64 + lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            a.ws.de_q[(int64_t)(b0 + 4 * g + r) * E_DIM + n] = deacc[ti * 256 + (4 * g + r) * 16 + j];
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(mt * 4 + r) * 64] = accW1[mt][r];
+        s_dg += __shfl_xor(s_dg, 16, 64);
+        s_dg += __shfl_xor(s_dg, 32, 64);
+        s_db += __shfl_xor(s_db, 16, 64);
+        s_db += __shfl_xor(s_db, 32, 64);
+        mine[32 * 64] = s_dg;
+        mine[33 * 64] = s_db;
+    }
+    __syncthreads();
+    float *slab = a.ws.q_slabs + (int64_t)hd * Q_SLAB;
+    for (int idx = tid; idx < QB_ACC * 64; idx += 256) {
+        const int slot = idx >> 6, l = idx & 63;
+        const float v = ((red[(0 * QB_ACC + slot) * 64 + l] + red[(1 * QB_ACC + slot) * 64 + l]) +
+                         red[(2 * QB_ACC + slot) * 64 + l]) + red[(3 * QB_ACC + slot) * 64 + l];
+        const int lj = l & 15, lg = l >> 4;
+        if (slot < 32) {
+            const int mt = slot >> 2, r = slot & 3;        // row hh = 16*mt + 4*lg + r, col n = cs*16 + lj
+            slab[2 * E_DIM + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
+        } else if (lg == 0) {
+            if (slot == 32) slab[cs * 16 + lj] = v;            // d ln1_g
+            else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
+        }
     }
 }
 
@@ -324,15 +330,6 @@ __device__ __forceinline__ void q_slab_sum(const IqnArgs &a, int64_t i, const fl
     const int hd = (int)(i / per_head);
     const int64_t o = (i - (int64_t)hd * per_head) * 4;
     float4 s = *reinterpret_cast<const float4 *>(a.ws.q_slabs + (int64_t)hd * Q_SLAB + o);
-    float4 v[7];
-#pragma unroll
-    for (int c = 1; c < 8; ++c)
-        if (c < a.n_chunks) v[c - 1] = *reinterpret_cast<const float4 *>(a.ws.q_slabs + ((int64_t)c * a.n_heads + hd) * Q_SLAB + o);
-#pragma unroll
-    for (int c = 1; c < 8; ++c)
-        if (c < a.n_chunks) {
-            s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
-        }
     // parameter order inside a head: ln1_g | ln1_b | w1 (contiguous), the slab has the same order
     const int64_t po = a.off.head_base + (int64_t)hd * a.off.head_stride + a.off.h_ln1_g + o;
     if (kappa) {

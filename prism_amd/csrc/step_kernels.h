@@ -17,7 +17,7 @@ namespace prism {
 __host__ __device__ inline int front_extra_blocks(int use_iqn, int n_heads, int has_target) {
     int n = 0;
     if (use_iqn) n += H_DIM / 4 + PACK_BLOCKS * (1 + (has_target ? 1 : 0));
-    n += n_heads * (Q_PACK_BLOCKS_PER_HEAD * (1 + (has_target ? 1 : 0)) + H_DIM / 4 + 1);
+    n += n_heads * (Q_PACK_BLOCKS_PER_HEAD * (1 + (has_target ? 1 : 0)) + H_DIM / 4 + Q_NORM_PARTS);
     return n;
 }
 
@@ -42,7 +42,7 @@ __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float
             x -= PACK_BLOCKS;
         }
     }
-    const int per_head = Q_PACK_BLOCKS_PER_HEAD * (1 + (a.has_target ? 1 : 0)) + H_DIM / 4 + 1;
+    const int per_head = Q_PACK_BLOCKS_PER_HEAD * (1 + (a.has_target ? 1 : 0)) + H_DIM / 4 + Q_NORM_PARTS;
     const int hd = x / per_head;
     x -= hd * per_head;
     if (x < Q_PACK_BLOCKS_PER_HEAD) {
@@ -61,7 +61,7 @@ __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float
         q_uv_block(a, hd, x * 4 + (tid >> 6), tid & 63);
         return;
     }
-    q_head_norm_block(a, hd, s_red);
+    q_head_norm_block(a, hd, x - H_DIM / 4, s_red);
 }
 
 __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red) { front_extra_block(a, x, s_red); }
@@ -214,6 +214,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
     __shared__ float s_red[64];
     __shared__ float s_kappa[Q_MAX_HEADS];
+    __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const int n_conv = (B + CONV_SPB - 1) / CONV_SPB;
     int blk = blockIdx.x;
@@ -287,10 +288,11 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
                 } else if (tid == 0) {
                     mw = (float)B;
                 }
+                stage_head_norms(a, s_parts, s_norm2);
                 const float tot = block_sum_1024(mw, s_red);
                 if (tid == 0) {
                     float c[Q_MAX_HEADS], theil;
-                    theil_factors(a.ws.q_kappa + Q_MAX_HEADS, a.n_heads, c, theil);
+                    theil_factors(s_norm2, a.n_heads, c, theil);
                     const float f = -a.q_w * a.theil_coef * (tot / (float)B);
                     for (int h = 0; h < a.n_heads; ++h) s_kappa[h] = f * c[h];
                 }
