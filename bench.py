@@ -199,27 +199,38 @@ def main():
         for i in range(N.N_KERNEL_IDS):
             if cnt[i]:
                 kern[L.prism_profile_kernel_name(i).decode()] = ms[i] / cnt[i] * 1e3     # us per launch
-        fl = kernel_flops(cfg, cfg.batch_size)
-        dom = max(fl, key=lambda k: kern.get(k, 0.0)) if kern else None
-        roof = None
+        fl = {k: v for k, v in kernel_flops(cfg, cfg.batch_size).items() if v}
         P = agent.flat.numel()
         P_tgt = P if cfg.use_target_network else 0
         levels = int(np.log2(buf.tree_capacity))
         abytes = algorithmic_bytes(cfg, P, P_tgt, levels)
         step_s = elapsed / args.steps
-        if dom and kern.get(dom):
-            ach = fl[dom] / (kern[dom] * 1e-6) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(f"c{args.config}", {}).get(dom)
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "flops_per_launch": fl[dom], "us_per_launch": round(kern[dom], 3),
-                    "kernel_us": {k: round(v, 3) for k, v in kern.items()},
-                    "step_hbm": {"algorithmic_bytes": abytes, "achieved_GBps": round(abytes / step_s / 1e9, 2),
-                                 "peak_GBps": HBM_PEAK_GBS, "frac": round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 5)},
-                    "step_mfma_frac": round(sum(fl.values()) / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        Bsz = cfg.batch_size
+        kbytes = {"step_front_kernel": Bsz * (8 * 400 + 17) + Bsz * (4 * levels + 16),
+                  "step_back_kernel": 24 * P + 4 * Bsz + 2 * Bsz * (4 + 12 * levels)}
+        traffic_all = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic_all = json.load(open(tpath)).get(f"c{args.config}", {})
+        roof = None
+        if kern:
+            mf = [k for k in fl if kern.get(k)]
+            if mf:      # a GEMM kernel dominates: fp32-MFMA roofline
+                dom = max(mf, key=lambda k: kern[k])
+                ach = fl[dom] / (kern[dom] * 1e-6) / 1e12
+                roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": traffic_all.get(dom), "flops_per_launch": fl[dom]}
+            else:       # DQN configurations: no GEMM; the longest kernel is a latency-bound byte mover
+                dom = max((k for k in kern if k in kbytes), key=lambda k: kern[k])
+                ach = kbytes[dom] / (kern[dom] * 1e-6) / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom),
+                        "bytes_per_launch": kbytes[dom]}
+            roof.update({"us_per_launch": round(kern[dom], 3), "kernel_us": {k: round(v, 3) for k, v in kern.items()},
+                         "step_hbm": {"algorithmic_bytes": abytes, "achieved_GBps": round(abytes / step_s / 1e9, 2),
+                                      "peak_GBps": HBM_PEAK_GBS, "frac": round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 5)},
+                         "step_mfma_frac": round(sum(fl.values()) / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)})
         out = {"metric": "learner grad-steps/sec, IQN+PER batch=256, 1/2/4/8 MI355X" if args.config == 2
                else f"learner grad-steps/sec, BASELINE configs[{args.config}]",
                "value": round(args.steps * world / elapsed, 2), "unit": "steps/s", "n_gpus": world,

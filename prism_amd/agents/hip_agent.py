@@ -267,7 +267,7 @@ class HipAgent:
             if self.dims.has_target:
                 taus.append(torch.rand([Tn * B, 1], device=self.device))
         d.tau_cur = d.tau_next_online = d.tau_next_target = None
-        if taus is not None:
+        if taus is not None and len(taus) > 0 and self.dims.use_iqn:
             ts = [t.to(self.device, torch.float32).reshape(-1).contiguous() for t in taus]
             keep.extend(ts)
             it = iter(ts)

@@ -78,6 +78,7 @@ struct IqnArgs {
     int n_chunks;          // row chunks of the backward
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
+    int head_layers;       // 2: LN-Linear-ReLU-LN-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
     unsigned long long *stamps;   // diagnostic builds only: [block][16] shader-clock stamps (dbg & 8)

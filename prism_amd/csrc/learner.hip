@@ -150,7 +150,8 @@ static constexpr int N_CHUNKS = BWD_CHUNKS;
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
-    if (d->embed_dim != E_DIM || !d->use_layer_norm) return PRISM_ERR_UNSUPPORTED;
+    if (d->embed_dim != E_DIM) return PRISM_ERR_UNSUPPORTED;
+    if (d->use_iqn && !d->use_layer_norm) return PRISM_ERR_UNSUPPORTED;
     if (d->use_iqn) {
         if (d->n_basis != K_BASIS || d->iqn_layers != 1 || d->iqn_width != H_DIM) return PRISM_ERR_UNSUPPORTED;
         if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
@@ -158,9 +159,15 @@ static int iqn_supported(const prism_model_dims *d, int32_t B) {
     }
     if (d->n_heads != 0) {
         // ensemble / DQN heads of the form LN -> Linear(1024,128) -> ReLU -> LN -> Linear(128,A)
-        if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || d->head_width != H_DIM)
-            return PRISM_ERR_UNSUPPORTED;
-        if (B % 16) return PRISM_ERR_UNSUPPORTED;
+        if (d->head_layers == 1) {
+            // single Linear(1024 -> A) DQN head, with or without LayerNorm, no IQN beside it
+            if (d->n_heads != 1 || d->use_iqn) return PRISM_ERR_UNSUPPORTED;
+        } else {
+            if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || d->head_width != H_DIM ||
+                !d->use_layer_norm)
+                return PRISM_ERR_UNSUPPORTED;
+            if (B % 16) return PRISM_ERR_UNSUPPORTED;
+        }
     }
     if (B < 1 || B > SMALL_MAX_B) return PRISM_ERR_UNSUPPORTED;
     if (d->n_actions < 1 || d->n_actions > 16 || d->in_channels < 1 || d->in_channels > 10) return PRISM_ERR_UNSUPPORTED;
@@ -220,7 +227,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
         w.q_wpk[0] = c.f(Hd * (size_t)H_DIM * E_DIM);
         w.q_wpk[1] = c.f(d->has_target ? Hd * (size_t)H_DIM * E_DIM : 0);
-        w.de_q = c.f(Hd * (size_t)B * E_DIM);
+        w.de_q = c.f(Hd * (size_t)B * E_DIM);      // (one slot for the single-Linear DQN head)
         w.q_slabs = c.f(Hd * (size_t)Q_SLAB);
     }
     float *tb = c.f(3 * maxT * B);
@@ -263,9 +270,11 @@ static int check_learner(const prism_learner_desc *ld) {
                     "parameter / gradient / Adam buffers must be 16-byte aligned");
     PRISM_CHECK_ARG(ld->off.n_params > 0 && (!ld->dims.use_iqn || (ld->off.phi_w & 3) == 0),
                     "n_params / phi_w offset alignment");
-    PRISM_CHECK_ARG(ld->dims.n_heads == 0 || (ld->off.head_base >= 0 && ld->off.h_w1 >= 0 && ld->off.h_w2 >= 0 &&
-                                              ld->off.h_ln1_g >= 0 && ld->off.h_ln2_g >= 0),
+    PRISM_CHECK_ARG(ld->dims.n_heads == 0 || (ld->off.head_base >= 0 && ld->off.h_w1 >= 0 && ld->off.h_b1 >= 0),
                     "Q-head parameter offsets missing");
+    PRISM_CHECK_ARG(ld->dims.n_heads == 0 || ld->dims.head_layers == 1 ||
+                        (ld->off.h_w2 >= 0 && ld->off.h_ln1_g >= 0 && ld->off.h_ln2_g >= 0),
+                    "two-layer Q-head parameter offsets missing");
     PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
                     "null batch arrays");
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
@@ -291,6 +300,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.dist_w = d.dist_loss_weight;
     a.use_iqn = d.use_iqn;
     a.n_heads = d.n_heads;
+    a.head_layers = d.head_layers;
     a.q_w = d.q_loss_weight;
     a.theil_coef = d.n_heads > 1 ? d.theil_coef : 0.f;
     { const char *e = getenv("PRISM_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -333,7 +343,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
         if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
         else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
     }
-    if (d.n_heads > 0) {
+    if (d.n_heads > 0 && d.head_layers == 2) {
         // Q-head tiles: (B/16) x heads per pass; same online/target selection (q_ensemble.py:62-68)
         const int nt = (B / 16) * d.n_heads;
         a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_cur, nullptr, a.ws.zq_cur, 1, nt, 1, 0, 1};
@@ -404,11 +414,12 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     if (!ld->embed_done) {
         ProfileScope ps_(K_EMBED, stream);
         hipLaunchKernelGGL(iqn_embed_kernel,
-                           dim3(2 * B + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target)), dim3(256),
+                           dim3(2 * B + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target, ld->dims.head_layers)),
+                           dim3(256),
                            0, stream, a);
         PRISM_CHECK_LAUNCH();
     }
-    {
+    if (total_tiles > 0) {
         ProfileScope ps_(K_TILE_FWD, stream);
         hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
         PRISM_CHECK_LAUNCH();
@@ -425,7 +436,11 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
             PRISM_CHECK_LAUNCH();
         }
     }
-    if (ld->dims.n_heads > 0) {
+    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 1) {
+        ProfileScope ps_(K_Q_FWD, stream);
+        hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    } else if (ld->dims.n_heads > 0) {
         {
             ProfileScope ps_(K_Q_FWD, stream);
             hipLaunchKernelGGL(qh_loss_kernel, dim3(B), dim3(512), 0, stream, a);
@@ -440,7 +455,9 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     }
     {
         ProfileScope ps_(K_POST, stream);
-        hipLaunchKernelGGL(iqn_post_kernel, dim3(post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads)), dim3(1024), 0, stream, a);
+        const int nb = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(B)
+                                                                     : post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads);
+        hipLaunchKernelGGL(iqn_post_kernel, dim3(nb), dim3(1024), 0, stream, a);
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dbg_z) {
@@ -454,7 +471,8 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
 // grid-norm partial slots valid for the Adam kernels: either what post left, or a fresh pass
 static int prepare_norm(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a, hipStream_t stream) {
     if (ld->hyper.grad_scale == 1.0f) {
-        a.n_slots = post_blocks(ld->batch, ld->dims.use_iqn, ld->dims.n_heads);   // single replica: reuse the post kernel's partials
+        a.n_slots = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(ld->batch)
+                                                                  : post_blocks(ld->batch, ld->dims.use_iqn, ld->dims.n_heads);
     } else {
         // data parallel: the gradient was all-reduced after the backward; recompute the partials
         const int nb = 256;
@@ -523,7 +541,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     {
         ProfileScope ps_(K_FRONT, stream);
         hipLaunchKernelGGL(step_front_kernel,
-                           dim3(ld->batch + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target)),
+                           dim3(ld->batch + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target, ld->dims.head_layers)),
                            dim3(256), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }

@@ -421,3 +421,269 @@ __device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, i
 }
 
 }  // namespace prism
+
+// ==========================================================================================
+// One-layer DQN head: Q = [LayerNorm(1024)](e) . W^T + b with W [A][1024]
+// (q_ensemble.py:25-38 with n_model_layers = 1 through FFNNModel, n_heads = 1; model_factory.py:130-145).
+// Everything is tiny (A dot products of length 1024 per observation), so there is no MFMA here: one
+// workgroup per sample for loss + input gradient, and a reduction role in the post kernel for dW.
+// ==========================================================================================
+namespace prism {
+
+// 1024-float dot products of one observation embedding against the A rows of W: 256 threads.
+// x in LDS (already normalised if LN), W in global; results -> out[A] (LDS), all threads return after a barrier.
+__device__ __forceinline__ void dqn_q_values(const float *s_x, const float *W, const float *bias, int A, float *s_out,
+                                             float *s_red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int aa = 0; aa < A; ++aa) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = tid + 256 * i;
+            s += s_x[n] * W[aa * E_DIM + n];
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_red[aa * 4 + w] = s;
+    }
+    __syncthreads();
+    if (tid < A) s_out[tid] = ((s_red[tid * 4] + s_red[tid * 4 + 1]) + (s_red[tid * 4 + 2] + s_red[tid * 4 + 3])) + bias[tid];
+    __syncthreads();
+}
+
+// LayerNorm(1024) of a row held in LDS (in place -> y = xhat*g + beta); returns mean / rstd; keeps xhat in s_xhat
+__device__ __forceinline__ void dqn_layernorm(float *s_x, float *s_xhat, const float *g, const float *be, float &mean,
+                                              float &rstd, float *s_red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float x[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = s_x[tid + 256 * i];
+        s += x[i];
+    }
+    s = wave_sum(s);
+    if (lane == 0) s_red[w] = s;
+    __syncthreads();
+    mean = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * (1.0f / E_DIM);
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] -= mean;
+        v += x[i] * x[i];
+    }
+    v = wave_sum(v);
+    if (lane == 0) s_red[w] = v;
+    __syncthreads();
+    rstd = 1.0f / sqrtf(((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * (1.0f / E_DIM) + LN_EPS);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = tid + 256 * i;
+        const float xh = x[i] * rstd;
+        s_xhat[n] = xh;
+        s_x[n] = xh * g[n] + be[n];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
+    __shared__ float s_x[E_DIM], s_xhat[E_DIM], s_nx[E_DIM], s_tmp[E_DIM];
+    __shared__ float s_q[16], s_qo[16], s_qt[16], s_red[64];
+    __shared__ float s_sc[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = a.B, A = a.A;
+    const bool ln = a.off.h_ln1_g >= 0;
+    const float *P = a.params + a.off.head_base, *Pt = (a.has_target ? a.target_params : a.params) + a.off.head_base;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_x[tid + 256 * i] = a.ws.e_cur[(int64_t)b * E_DIM + tid + 256 * i];
+        s_nx[tid + 256 * i] = a.ws.e_next[(int64_t)b * E_DIM + tid + 256 * i];
+    }
+    __syncthreads();
+    float mean = 0.f, rstd = 1.f;
+    if (ln) dqn_layernorm(s_x, s_xhat, P + a.off.h_ln1_g, P + a.off.h_ln1_b, mean, rstd, s_red);
+    dqn_q_values(s_x, P + a.off.h_w1, P + a.off.h_b1, A, s_q, s_red);
+    // next-state values: online (no target, or double-Q) and/or target (q_ensemble.py:62-68)
+    const bool need_on = !a.has_target || a.double_q;
+    if (need_on) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_tmp[tid + 256 * i] = s_nx[tid + 256 * i];
+        __syncthreads();
+        float m2, r2;
+        if (ln) dqn_layernorm(s_tmp, s_xhat + 0, P + a.off.h_ln1_g, P + a.off.h_ln1_b, m2, r2, s_red);   // xhat of cur is re-made below
+        dqn_q_values(s_tmp, P + a.off.h_w1, P + a.off.h_b1, A, s_qo, s_red);
+    }
+    if (a.has_target) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_tmp[tid + 256 * i] = s_nx[tid + 256 * i];
+        __syncthreads();
+        float m2, r2;
+        if (ln) dqn_layernorm(s_tmp, s_xhat + 0, Pt + a.off.h_ln1_g, Pt + a.off.h_ln1_b, m2, r2, s_red);
+        dqn_q_values(s_tmp, Pt + a.off.h_w1, Pt + a.off.h_b1, A, s_qt, s_red);
+    }
+    if (ln && (need_on || a.has_target)) {   // restore xhat of the CURRENT observation (clobbered above)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = tid + 256 * i;
+            s_xhat[n] = (a.ws.e_cur[(int64_t)b * E_DIM + n] - mean) * rstd;
+        }
+        __syncthreads();
+    }
+    const int act = (int)a.action[b];
+    if (tid == 0) {
+        const float *qon = need_on ? s_qo : s_qt, *qtg = a.has_target ? s_qt : s_qo;
+        int best = 0;
+        float bv = qon[0];
+        for (int aa = 1; aa < A; ++aa)
+            if (qon[aa] > bv) {
+                bv = qon[aa];
+                best = aa;
+            }
+        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+        const float y = a.reward[b] + qtg[best] * dg;
+        const float diff = s_q[act] - y;
+        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+        const float ql = a.q_w * (diff * diff);
+        a.out_ql[b] = ql;
+        a.ws.q_lossw[b] = ql * wb;
+        a.out_td[b] = fabsf(ql);                       // composite_model.py:141-142
+        const float dq = (wb / (float)B) * a.q_w * 2.0f * diff;
+        a.ws.q_dq[b] = dq;
+        s_sc[0] = dq;
+        if (ln) {
+            a.ws.q_mu1[b] = mean;
+            a.ws.q_rstd1[b] = rstd;
+        }
+        if (b == 0) a.out_scalars[4] = 0.f;
+    }
+    __syncthreads();
+    // input gradient: dy = dq * W[act]; through LayerNorm if present; masked by the conv ReLU later
+    const float dq = s_sc[0];
+    const float *Wa = P + a.off.h_w1 + (int64_t)act * E_DIM;
+    float dy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dy[i] = dq * Wa[tid + 256 * i];
+    if (ln) {
+        const float *g = P + a.off.h_ln1_g;
+        float s1 = 0.f, s2 = 0.f, dxh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = tid + 256 * i;
+            dxh[i] = dy[i] * g[n];
+            s1 += dxh[i];
+            s2 += dxh[i] * s_xhat[n];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            s_red[w] = s1;
+            s_red[4 + w] = s2;
+        }
+        __syncthreads();
+        const float m1 = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * (1.0f / E_DIM);
+        const float m2 = ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) * (1.0f / E_DIM);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = tid + 256 * i;
+            a.ws.de_q[(int64_t)b * E_DIM + n] = rstd * (dxh[i] - m1 - s_xhat[n] * m2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a.ws.de_q[(int64_t)b * E_DIM + tid + 256 * i] = dy[i];
+    }
+}
+
+// post role: dW[a][n] = sum_{b: act=a} dq_b * y_b[n], db[a], and with LayerNorm dg[n] = sum_b dy_b[n] xhat_b[n],
+// dbeta[n] = sum_b dy_b[n] (dy_b = dq_b W[act_b]).  1024 threads = 128 columns x 8 batch parts; 8 blocks.
+constexpr int DQN_GRAD_BLOCKS = E_DIM / 128;
+
+__device__ __forceinline__ void dqn_grad_block(const IqnArgs &a, int slice, float &sq) {
+    __shared__ float s_part[8][128];
+    const int tid = threadIdx.x, B = a.B, A = a.A;
+    const int nl = tid & 127, part = tid >> 7, n = slice * 128 + nl;
+    const bool ln = a.off.h_ln1_g >= 0;
+    const float *P = a.params + a.off.head_base;
+    float *G = a.grads + a.off.head_base;
+    const float gn = ln ? P[a.off.h_ln1_g + n] : 1.f, bn = ln ? P[a.off.h_ln1_b + n] : 0.f;
+    float sA[16];
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
+    float dgs = 0.f, dbs = 0.f;
+#pragma unroll 4
+    for (int b = part; b < B; b += 8) {
+        const float dq = a.ws.q_dq[b];
+        const int ab = (int)a.action[b];
+        const float e = a.ws.e_cur[(int64_t)b * E_DIM + n];
+        float y = e;
+        if (ln) {
+            const float xh = (e - a.ws.q_mu1[b]) * a.ws.q_rstd1[b];
+            y = xh * gn + bn;
+            const float dy = dq * P[a.off.h_w1 + (int64_t)ab * E_DIM + n];
+            dgs += dy * xh;
+            dbs += dy;
+        }
+        const float v = dq * y;
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
+    }
+#pragma unroll
+    for (int aa = 0; aa < 16; ++aa) {
+        if (aa < A) {
+            __syncthreads();
+            s_part[part][nl] = sA[aa];
+            __syncthreads();
+            if (part == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) t += s_part[p][nl];
+                G[a.off.h_w1 + (int64_t)aa * E_DIM + n] = t;
+                sq += t * t;
+            }
+        }
+    }
+    if (ln) {
+        __syncthreads();
+        s_part[part][nl] = dgs;
+        __syncthreads();
+        if (part == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t += s_part[p][nl];
+            G[a.off.h_ln1_g + n] = t;
+            sq += t * t;
+        }
+        __syncthreads();
+        s_part[part][nl] = dbs;
+        __syncthreads();
+        if (part == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t += s_part[p][nl];
+            G[a.off.h_ln1_b + n] = t;
+            sq += t * t;
+        }
+    }
+    if (slice == 0) {
+        // db[a] = sum_{b: act=a} dq_b (one wave per action), total loss = mean(ql * w)
+        const int aa = tid >> 6, lane = tid & 63;
+        float s = 0.f, lw = 0.f;
+        if (aa < A)
+            for (int b = lane; b < B; b += 64) s += ((int)a.action[b] == aa) ? a.ws.q_dq[b] : 0.f;
+        if (aa == 15)
+            for (int b = lane; b < B; b += 64) lw += a.ws.q_lossw[b];
+        s = wave_sum(s);
+        lw = wave_sum(lw);
+        if (lane == 0 && aa < A) {
+            G[a.off.h_b1 + aa] = s;
+            sq += s * s;
+        }
+        if (lane == 0 && aa == 15) {
+            const float l = lw / (float)B;
+            a.out_scalars[0] = l;
+            a.out_scalars[1] = 0.f;
+            a.out_scalars[2] = l;
+        }
+    }
+}
+
+}  // namespace prism

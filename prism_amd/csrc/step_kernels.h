@@ -14,8 +14,9 @@ namespace prism {
 // ---- the parameter-only roles that ride along with the embed / front launch ---------------------
 // IQN: u,v (H/4 blocks), weight packing (PACK_BLOCKS, x2 with a target network);
 // Q heads: per head W1 packing (x2 with target), u_h,v_h (H/4 blocks), ||theta_h||^2 (1 block).
-__host__ __device__ inline int front_extra_blocks(int use_iqn, int n_heads, int has_target) {
+__host__ __device__ inline int front_extra_blocks(int use_iqn, int n_heads, int has_target, int head_layers = 2) {
     int n = 0;
+    if (head_layers == 1) n_heads = 0;        // single-Linear DQN head: nothing to pack or precompute
     if (use_iqn) n += H_DIM / 4 + PACK_BLOCKS * (1 + (has_target ? 1 : 0));
     n += n_heads * (Q_PACK_BLOCKS_PER_HEAD * (1 + (has_target ? 1 : 0)) + H_DIM / 4 + Q_NORM_PARTS);
     return n;
@@ -195,6 +196,8 @@ __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads) {
     if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_SMALL_BLOCKS;
     return n;
 }
+__host__ __device__ inline int post_blocks_dqn1(int B) { return (B + CONV_SPB - 1) / CONV_SPB + DQN_GRAD_BLOCKS;
+}
 
 __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     const int tid = threadIdx.x;
@@ -276,6 +279,10 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
             } else {
                 blk -= POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
             }
+        }
+        if (!done && a.head_layers == 1) {
+            dqn_grad_block(a, blk, sq);
+            done = true;
         }
         if (!done) {
             // Q-head roles.  Theil gradient factor per head: dL/dtheta += kappa_h * theta with

@@ -10,11 +10,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _mk(dev, fused, graph, B=32, cap=4096, **over):
+def _mk(dev, fused, graph, B=32, cap=4096, base=2, **over):
     from prism_amd.config import baseline_config
     from prism_amd.learner import Learner
     from prism_amd.synthetic import fill_replay
-    cfg = baseline_config(2, device=dev, batch_size=B, experience_replay_capacity=cap, **over)
+    cfg = baseline_config(base, device=dev, batch_size=B, experience_replay_capacity=cap, **over)
     cfg.fused_step, cfg.hip_graph = fused, graph
     ln = Learner()
     with contextlib.redirect_stdout(io.StringIO()):
@@ -23,7 +23,9 @@ def _mk(dev, fused, graph, B=32, cap=4096, **over):
     return ln
 
 
-@pytest.mark.parametrize("over", [dict(), dict(use_target_network=True, target_update_period=2)])
+@pytest.mark.parametrize("over", [dict(), dict(use_target_network=True, target_update_period=2),
+                                  dict(base=0), dict(base=1), dict(base=3, target_update_period=3),
+                                  dict(base=1, use_layer_norm=True, use_double_q_learning=True, use_target_network=True)])
 def test_fused_and_graph_equal_unfused(over):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -35,8 +37,9 @@ def test_fused_and_graph_equal_unfused(over):
             td = ln.step(timesteps_this_iteration=1).clone()
             torch.cuda.synchronize()
             buf, ag = ln.experience_buffer, ln.agent
+            tree = buf.sum_tree.cpu().numpy() if buf.use_per else np.zeros(1)
             outs.append((td.cpu().numpy(), buf._index.cpu().numpy(), buf._weight.cpu().numpy(),
-                         ag.flat.cpu().numpy(), buf.sum_tree.cpu().numpy(), float(ag.scalars[0]),
+                         ag.flat.cpu().numpy(), tree, float(ag.scalars[0]),
                          buf._obs.cpu().numpy(), buf._reward.cpu().numpy()))
         for other in outs[1:]:
             for x, y in zip(outs[0], other):
