@@ -208,6 +208,13 @@ typedef struct prism_learner_desc {
     uint64_t *rng_counters;   /* optional device [2] {PER draws, tau draws} added to the immediate offsets
                                  and advanced by prism_step_back (lets a captured hipGraph draw fresh
                                  numbers on every replay); NULL = immediate offsets only              */
+    /* Optional: when fused_replay is set, prism_learner_fwd_bwd also performs
+     * prism_per_update(fused_index, |out_td|) as one more workgroup of its last launch (the TD errors
+     * are final by then, and the writeback hides behind the gradient reduction), and prism_step_back
+     * skips its own writeback.  Results are identical. */
+    const struct prism_replay_desc *fused_replay;   /* host pointer or NULL */
+    const int64_t *fused_index;                     /* [B] sampled slots */
+    float fused_alpha, fused_eps;
     /* outputs */
     float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */
     float *out_q_loss;        /* [B] or NULL  (Agent._static_q_loss)                          */

@@ -179,6 +179,7 @@ class HipAgent:
         self.dims = model_dims(config, in_channels, n_actions)
         self.off = _offsets(model)
         self.tau_rng = getattr(config, "tau_rng", "philox")
+        self.overlap_writeback = bool(getattr(config, "overlap_writeback", True))
         self.seed = int(config.seed)
         self._draw_offset = 0
         self.pg = process_group
@@ -277,7 +278,7 @@ class HipAgent:
             if self.dims.has_target:
                 d.tau_next_target = next(it).data_ptr()
         d.offset = self._draw_offset
-        d.rng_counters, d.embed_done = None, 0
+        d.rng_counters, d.embed_done, d.fused_replay = None, 0, None
         self._draw_offset += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * B
         self._set_hyper()
         L = N.lib()
@@ -311,6 +312,12 @@ class HipAgent:
     def _launch_fused(self, buf, d, part="all"):
         L, st = N.lib(), N.current_stream_handle
         rp = ctypes.byref(buf._desc)
+        smp = buf.buffer._sampler
+        if buf.use_per and self.overlap_writeback:
+            d.fused_replay = ctypes.cast(ctypes.pointer(buf._desc), ctypes.c_void_p)
+            d.fused_index, d.fused_alpha, d.fused_eps = buf._index.data_ptr(), smp._alpha, smp._eps
+        else:
+            d.fused_replay = None
         if part in ("all", "front"):
             d.embed_done = 1
             N.check(L.prism_step_front(ctypes.byref(d), rp, buf._size, None, buf.seed, d.offset,
@@ -321,7 +328,6 @@ class HipAgent:
         if part == "all" and self.world > 1:
             pdist.allreduce_grads(self.grads, self.pg)
         if part in ("all", "back"):
-            smp = buf.buffer._sampler
             N.check(L.prism_step_back(ctypes.byref(d), rp, N.ptr(buf._index), smp._alpha, smp._eps, st()),
                     "prism_step_back")
 

@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) { clip_adam_
 // back: block 0 = priority writeback (+ RNG counters); blocks [1, gridDim) = clip + Adam.
 __global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay_desc rp, BackArgs k) {
     if (blockIdx.x == 0) {
-        if (k.use_per) per_update_block(rp, k.index, k.priority, k.n, k.alpha, k.eps, k.take_abs);
+        __shared__ __attribute__((aligned(16))) char s_pool[PER_UPDATE_LDS_BYTES];
+        if (k.use_per) per_update_block(rp, k.index, k.priority, k.n, k.alpha, k.eps, k.take_abs, s_pool);
         if (k.rng && threadIdx.x == 0) {
             k.rng[0] += k.inc_per;
             k.rng[1] += k.inc_tau;
@@ -424,40 +425,46 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
         PRISM_CHECK_LAUNCH();
     }
+    // losses first (TD errors final), then fork the priority writeback, then the backward kernels
     if (ld->dims.use_iqn) {
-        {
-            ProfileScope ps_(K_LOSS, stream);
-            hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
-            PRISM_CHECK_LAUNCH();
-        }
-        {
-            ProfileScope ps_(K_BWD, stream);
-            hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
-            PRISM_CHECK_LAUNCH();
-        }
-    }
-    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 1) {
-        ProfileScope ps_(K_Q_FWD, stream);
-        hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
+        ProfileScope ps_(K_LOSS, stream);
+        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
         PRISM_CHECK_LAUNCH();
-    } else if (ld->dims.n_heads > 0) {
-        {
-            ProfileScope ps_(K_Q_FWD, stream);
-            hipLaunchKernelGGL(qh_loss_kernel, dim3(B), dim3(512), 0, stream, a);
-            PRISM_CHECK_LAUNCH();
-        }
-        {
-            ProfileScope ps_(K_Q_BWD, stream);
-            hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * ld->dims.n_heads), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
-                               a);
-            PRISM_CHECK_LAUNCH();
-        }
+    }
+    if (ld->dims.n_heads > 0) {
+        ProfileScope ps_(K_Q_FWD, stream);
+        if (ld->dims.head_layers == 1) hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(qh_loss_kernel, dim3(B), dim3(512), 0, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    if (ld->dims.use_iqn) {
+        ProfileScope ps_(K_BWD, stream);
+        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+        PRISM_CHECK_LAUNCH();
+    }
+    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2) {
+        ProfileScope ps_(K_Q_BWD, stream);
+        hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * ld->dims.n_heads), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
+                           a);
+        PRISM_CHECK_LAUNCH();
     }
     {
         ProfileScope ps_(K_POST, stream);
-        const int nb = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(B)
-                                                                     : post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads);
-        hipLaunchKernelGGL(iqn_post_kernel, dim3(nb), dim3(1024), 0, stream, a);
+        int nb = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(B)
+                                                               : post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads);
+        PostWriteback wb;
+        memset(&wb, 0, sizeof(wb));
+        if (ld->fused_replay && ld->fused_replay->sum_tree && ld->fused_index) {
+            // TD errors are final: the priority writeback rides along as one more block of this launch
+            wb.enabled = 1;
+            wb.rp = *ld->fused_replay;
+            wb.index = ld->fused_index;
+            wb.alpha = ld->fused_alpha;
+            wb.eps = ld->fused_eps;
+            wb.block = nb;
+            nb += 1;
+        }
+        hipLaunchKernelGGL(iqn_post_kernel, dim3(nb), dim3(1024), 0, stream, a, wb);
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dbg_z) {
@@ -569,7 +576,7 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
     k.alpha = alpha;
     k.eps = eps;
     k.take_abs = 1;
-    k.use_per = rp->sum_tree != nullptr;
+    k.use_per = rp->sum_tree != nullptr && !ld->fused_replay;   // already written back beside the backward pass
     k.rng = ld->rng_counters;
     const int maxT = ld->dims.n_tau > ld->dims.n_tau_next ? ld->dims.n_tau : ld->dims.n_tau_next;
     k.inc_per = (uint64_t)ld->batch;

@@ -149,14 +149,18 @@ constexpr int UPD_MAX = 1024;  // leaves per pass of the single-workgroup writer
 constexpr int HT_BITS = 11, HT_SIZE = 1 << HT_BITS;   // duplicate-detection hash table (load factor <= 0.5)
 
 // whole PrioritizedSampler.update_priority for one batch, executed by ONE workgroup (any size)
+// `lds`: PER_UPDATE_LDS_BYTES of 16-byte aligned LDS supplied by the calling kernel (so that kernels
+// hosting this routine as one role among others can alias it with their own scratch).
+constexpr int PER_UPDATE_LDS_BYTES = UPD_MAX * 4 + UPD_MAX * 4 + UPD_MAX + 64 + 2 * (2 * WTOP) * 4 + 2 * HT_SIZE * 4;
 __device__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
-                                 const float *__restrict__ priority, int n, float alpha, float eps, int take_abs) {
-    __shared__ __attribute__((aligned(16))) int32_t s_idx[UPD_MAX];
-    __shared__ float s_val[UPD_MAX];
-    __shared__ uint8_t s_win[UPD_MAX];
-    __shared__ float s_red[16];
-    __shared__ float s_tsum[2 * WTOP], s_tmin[2 * WTOP];
-    __shared__ int32_t s_hkey[HT_SIZE], s_hpos[HT_SIZE];
+                                 const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
+                                 char *lds) {
+    int32_t *s_idx = reinterpret_cast<int32_t *>(lds);
+    float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);
+    float *s_red = reinterpret_cast<float *>(lds + UPD_MAX * 8);
+    float *s_tsum = s_red + 16, *s_tmin = s_tsum + 2 * WTOP;
+    int32_t *s_hkey = reinterpret_cast<int32_t *>(s_tmin + 2 * WTOP), *s_hpos = s_hkey + HT_SIZE;
+    uint8_t *s_win = reinterpret_cast<uint8_t *>(s_hpos + HT_SIZE);
     // running max of the raw priorities (torchrl tracks it before the +eps, **alpha)
     float m = -FLT_MAX;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -220,7 +224,8 @@ __device__ void per_update_block(const prism_replay_desc &rp, const int64_t *__r
 static __global__ __launch_bounds__(1024) void per_update_kernel(prism_replay_desc rp, const int64_t *__restrict__ index,
                                                          const float *__restrict__ priority, int n,
                                                          float alpha, float eps, int take_abs) {
-    per_update_block(rp, index, priority, n, alpha, eps, take_abs);
+    __shared__ __attribute__((aligned(16))) char s_pool[PER_UPDATE_LDS_BYTES];
+    per_update_block(rp, index, priority, n, alpha, eps, take_abs, s_pool);
 }
 
 // rows of an insert batch -> ring slots (any number of workgroups)

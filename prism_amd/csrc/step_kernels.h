@@ -214,8 +214,23 @@ __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     return t;   // valid in thread 0
 }
 
-__global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
+struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as the last block of the post launch
+    prism_replay_desc rp;
+    const int64_t *index;
+    float alpha, eps;
+    int enabled, block;
+};
+
+__global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb) {
+    // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
+    constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_SPB * (1000 + 16 * 65) * sizeof(float))
+                             ? PER_UPDATE_LDS_BYTES : (int)(CONV_SPB * (1000 + 16 * 65) * sizeof(float));
+    __shared__ __attribute__((aligned(16))) char s_pool[POOL];
     __shared__ float s_red[64];
+    if (wb.enabled && (int)blockIdx.x == wb.block) {
+        per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool);
+        return;
+    }
     __shared__ float s_kappa[Q_MAX_HEADS];
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
@@ -223,10 +238,9 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a) {
     int blk = blockIdx.x;
     float sq = 0.f;
     if (blk < n_conv) {
-        __shared__ float s_obs[CONV_SPB][1000];
-        __shared__ float s_dc[CONV_SPB][16 * 65];
         __shared__ int s_last;
-        conv_bwd_partial_block(a, blk, &s_obs[0][0], &s_dc[0][0]);
+        float *s_obs = reinterpret_cast<float *>(s_pool), *s_dc = s_obs + CONV_SPB * 1000;
+        conv_bwd_partial_block(a, blk, s_obs, s_dc);
         // publish, then let the last arriver fold all partial rows: ONE lane releases after the
         // block's stores have drained (the barrier waits for them), ONE lane acquires
         __syncthreads();
