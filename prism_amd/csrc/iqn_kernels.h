@@ -894,8 +894,12 @@ constexpr int CONV_ROW = 16 * 90 + 16;   // floats per partial row: 16 * 9C weig
 constexpr int SMALL_MAX_B = 4096;
 
 // d conv_w / d conv_b partial sums over samples [cb*CONV_SPB, ...) for all 16 output channels.
-// s_obs: [CONV_SPB][1000] floats, s_dc: [CONV_SPB][16*65] floats of LDS.  1024 threads.
-__device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *s_obs, float *s_dc) {
+// lds: CONV_LDS_FLOATS floats: obs [CONV_SPB][1000] | dconv [CONV_SPB][16*65] | partials.  1024 threads.
+// Work item = (sample, out channel c, in channel ci, kernel row dy): its three dx outputs share every
+// LDS operand (10 observation values + 8 gradient values per image row feed 24 MACs).
+constexpr int CONV_LDS_FLOATS = CONV_SPB * (1000 + 16 * 65) + CONV_SPB * 16 * 10 * 3 * 3;
+__device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *lds) {
+    float *s_obs = lds, *s_dc = lds + CONV_SPB * 1000, *s_par = s_dc + CONV_SPB * 16 * 65;
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const int b0 = cb * CONV_SPB, ns = min(CONV_SPB, B - b0);
 #pragma unroll 2
@@ -912,21 +916,37 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
+    const int per_s = 16 * C * 3;                 // (c, ci, dy) groups per sample
+    for (int item = tid; item < ns * per_s; item += 1024) {
+        const int s = item / per_s, og = item - s * per_s;
+        const int c = og / (3 * C), r = og - c * 3 * C, ci = r / 3, dy = r - ci * 3;
+        const float *dc = &s_dc[s * (16 * 65) + c * 65];
+        const float *ob = &s_obs[s * 1000 + dy * 10 * C + ci];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            float row[10];
+#pragma unroll
+            for (int x = 0; x < 10; ++x) row[x] = ob[(y * 10 + x) * C];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float d = dc[y * 8 + x];
+                a0 = fmaf(d, row[x], a0);
+                a1 = fmaf(d, row[x + 1], a1);
+                a2 = fmaf(d, row[x + 2], a2);
+            }
+        }
+        s_par[item * 3 + 0] = a0;
+        s_par[item * 3 + 1] = a1;
+        s_par[item * 3 + 2] = a2;
+    }
+    __syncthreads();
     const int nk = 9 * C;
     float *out = a.ws.convpart + (int64_t)cb * CONV_ROW;
-    for (int o = tid; o < 16 * nk; o += 1024) {
-        const int c = o / nk, k = o - c * nk;
-        const int ci = k / 9, dy = (k % 9) / 3, dx = k % 3;
-        float acc = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            const float *dc = &s_dc[s * (16 * 65) + c * 65];
-            const float *ob = &s_obs[s * 1000 + (dy * 10 + dx) * C + ci];
-#pragma unroll
-            for (int y = 0; y < 8; ++y)
-#pragma unroll
-                for (int x = 0; x < 8; ++x) acc = fmaf(dc[y * 8 + x], ob[(y * 10 + x) * C], acc);
-        }
-        out[o] = acc;
+    for (int o = tid; o < 16 * nk; o += 1024) {   // o = c*9C + ci*9 + dy*3 + dx  ==  (c*3C + ci*3 + dy)*3 + dx
+        float t = 0.f;
+        for (int s = 0; s < ns; ++s) t += s_par[s * per_s * 3 + o];
+        out[o] = t;
     }
     if (tid < 16) {
         float acc = 0.f;
@@ -936,40 +956,42 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
     }
 }
 
-// b1, LN2 affine, W2, b2 gradients for the 64 hidden units [slice*64, slice*64+64).
+// b1, LN2 affine, W2, b2 gradients for the 16 hidden units [slice*16, slice*16+16).
 //   S[a][h] = sum_{b: act=a} Sb[b][h];  D[a] = sum_{b: act=a} Db[b];  db1[h] = sum_b Pb[b][h]
 //   dW2[a][h] = g2[h] S[a][h] + beta2[h] D[a];  dg2[h] = sum_a W2[a][h] S[a][h];  dbeta2[h] = sum_a W2[a][h] D[a]
-// 1024 threads = 64 units x 16 batch parts.  Slice 0 also writes db2 and the total loss.
+// 1024 threads = 16 units x 64 batch parts.  Slice 0 also writes db2 and the IQN part of the total loss.
+constexpr int SMALL_W = 16;
 __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq) {
-    __shared__ float s_part[16][64];
-    __shared__ float s_S[16][64];
+    __shared__ float s_part[64][SMALL_W];
+    __shared__ float s_S[16][SMALL_W];
     __shared__ float s_D[16];
     __shared__ float s_lw[16];
     const int tid = threadIdx.x, B = a.B, A = a.A;
-    const int hl = tid & 63, part = tid >> 6, h = slice * 64 + hl;
+    const int hl = tid & (SMALL_W - 1), part = tid >> 4, h = slice * SMALL_W + hl;
     float sA[16];
 #pragma unroll
     for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
     float pb = 0.f;
 #pragma unroll 4
-    for (int b = part; b < B; b += 16) {
+    for (int b = part; b < B; b += 64) {
         const float v = a.ws.Sb[(int64_t)b * H_DIM + h];
         pb += a.ws.Pb[(int64_t)b * H_DIM + h];
         const int ab = (int)a.action[b];
 #pragma unroll
         for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
     }
-    {   // D[a]: one wave per action (wave index == part)
+    {   // D[a]: one wave per action; slice 0 also sums the weighted losses
+        const int wv = tid >> 6, lane = tid & 63;
         float s = 0.f, lw = 0.f;
-        if (part < A)
-            for (int b = hl; b < B; b += 64) s += ((int)a.action[b] == part) ? a.ws.Db[b] : 0.f;
+        if (wv < A)
+            for (int b = lane; b < B; b += 64) s += ((int)a.action[b] == wv) ? a.ws.Db[b] : 0.f;
         if (slice == 0)
             for (int b = tid; b < B; b += 1024) lw += a.ws.lossw[b];
         s = wave_sum(s);
         lw = wave_sum(lw);
-        if (hl == 0) {
-            s_D[part] = s;
-            s_lw[part] = lw;
+        if (lane == 0) {
+            s_D[wv] = s;
+            s_lw[wv] = lw;
         }
     }
     float *gr = a.grads;
@@ -982,8 +1004,8 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
             __syncthreads();
             if (part == 0) {
                 float t = 0.f;
-#pragma unroll
-                for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+#pragma unroll 16
+                for (int p = 0; p < 64; ++p) t += s_part[p][hl];
                 s_S[aa][hl] = t;
             }
         }
@@ -993,8 +1015,8 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
     __syncthreads();
     if (part == 0) {
         float t = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) t += s_part[p][hl];
+#pragma unroll 16
+        for (int p = 0; p < 64; ++p) t += s_part[p][hl];
         gr[a.off.iqn_b1 + h] = t;
         sq += t * t;
         const float g2 = P[a.off.iqn_ln2_g + h], be2 = P[a.off.iqn_ln2_b + h];

@@ -187,13 +187,14 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
 // Every block leaves its sum of squares in normpart[blockIdx.x].
 // ------------------------------------------------------------------------------------------
 constexpr int POST_SLAB_BLOCKS = (SLAB / 4 + 1023) / 1024;   // 49
-constexpr int POST_SMALL_BLOCKS = H_DIM / 64;                // 2
+constexpr int POST_SMALL_BLOCKS = H_DIM / SMALL_W;           // 8 (IQN small tensors, 16 hidden units per block)
+constexpr int POST_QSMALL_BLOCKS = H_DIM / 64;               // 2 per head
 
 __host__ __device__ inline int post_q_slab_blocks(int n_heads) { return (n_heads * (Q_SLAB / 4) + 1023) / 1024; }
 __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads) {
     int n = (B + CONV_SPB - 1) / CONV_SPB;
     if (use_iqn) n += POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
-    if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_SMALL_BLOCKS;
+    if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_QSMALL_BLOCKS;
     return n;
 }
 __host__ __device__ inline int post_blocks_dqn1(int B) { return (B + CONV_SPB - 1) / CONV_SPB + DQN_GRAD_BLOCKS;
@@ -223,12 +224,14 @@ struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as 
 
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb) {
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
-    constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_SPB * (1000 + 16 * 65) * sizeof(float))
-                             ? PER_UPDATE_LDS_BYTES : (int)(CONV_SPB * (1000 + 16 * 65) * sizeof(float));
+    constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
+                                                                                       : (int)(CONV_LDS_FLOATS * sizeof(float));
     __shared__ __attribute__((aligned(16))) char s_pool[POOL];
     __shared__ float s_red[64];
+    PRISM_STAMP(13);
     if (wb.enabled && (int)blockIdx.x == wb.block) {
         per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool);
+        PRISM_STAMP(14);
         return;
     }
     __shared__ float s_kappa[Q_MAX_HEADS];
@@ -239,8 +242,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     float sq = 0.f;
     if (blk < n_conv) {
         __shared__ int s_last;
-        float *s_obs = reinterpret_cast<float *>(s_pool), *s_dc = s_obs + CONV_SPB * 1000;
-        conv_bwd_partial_block(a, blk, s_obs, s_dc);
+        conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
         // publish, then let the last arriver fold all partial rows: ONE lane releases after the
         // block's stores have drained (the barrier waits for them), ONE lane acquires
         __syncthreads();
@@ -255,14 +257,27 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         }
         __syncthreads();
         if (s_last) {
+            // fold all partial rows: item = (output, half of the rows), combined through LDS
             const int nk = 9 * C, n_out = 16 * nk + 16;
-            for (int o = tid; o < n_out; o += 1024) {
+            float *s_half = reinterpret_cast<float *>(s_pool);
+            const int hrows = (n_conv + 1) / 2;
+            for (int base = 0; base < n_out; base += 512) {
+                const int o = base + (tid & 511), half = tid >> 9;
                 float s = 0.f;
+                if (o < n_out) {
+                    const int r0 = half * hrows, r1 = min(n_conv, r0 + hrows);
 #pragma unroll 16
-                for (int ch = 0; ch < n_conv; ++ch) s += a.ws.convpart[(int64_t)ch * CONV_ROW + o];
-                if (o < 16 * nk) a.grads[a.off.conv_w + o] = s;
-                else a.grads[a.off.conv_b + (o - 16 * nk)] = s;
-                sq += s * s;
+                    for (int ch = r0; ch < r1; ++ch) s += a.ws.convpart[(int64_t)ch * CONV_ROW + o];
+                }
+                __syncthreads();
+                s_half[tid] = s;
+                __syncthreads();
+                if (half == 0 && o < n_out) {
+                    const float t = s_half[tid] + s_half[tid + 512];
+                    if (o < 16 * nk) a.grads[a.off.conv_w + o] = t;
+                    else a.grads[a.off.conv_b + (o - 16 * nk)] = t;
+                    sq += t * t;
+                }
             }
             if (tid == 0) a.ws.ticket[1] = 0u;
         }
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 if (i < (int64_t)a.n_heads * (Q_SLAB / 4)) q_slab_sum(a, i, kappa, sq);
             } else {
                 const int x = blk - nqs;
-                q_small_tensor_block(a, x / POST_SMALL_BLOCKS, x % POST_SMALL_BLOCKS, kappa, sq);
+                q_small_tensor_block(a, x / POST_QSMALL_BLOCKS, x % POST_QSMALL_BLOCKS, kappa, sq);
                 if (x == 0) {
                     // total loss (agent.py:58-64): mean(dl*w) [already in out_scalars[1]] + mean(ql*w)
                     float lw = 0.f;
@@ -346,6 +361,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     }
     const float t = block_sum_1024(sq, s_red);
     if (tid == 0) a.ws.normpart[blockIdx.x] = t;
+    PRISM_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -33,3 +33,20 @@ print(f"bwd ({nb} workgroups):")
 for k, name in enumerate(["consts", "tile loop", "barrier", "reduce+write"]):
     print(f"   {name:24s} {np.median(b[:, k + 1] - b[:, k]):9.0f}")
 print(f"   total {np.median(b[:, 4] - b[:, 0]):9.0f}   start spread {b[:, 0].max() - b[:, 0].min():9.0f}  end spread {b[:, 4].max() - b[:, 4].min():9.0f}")
+
+# post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
+B = cfg.batch_size
+n_conv = (B + 3) // 4
+pb = s[:, 13] != 0
+ps_, pe_ = s[pb, 13].astype(np.float64), s[pb, 14].astype(np.float64)
+idx = np.nonzero(pb)[0]
+t0 = ps_.min()
+print(f"post ({pb.sum()} blocks): span {pe_.max() - t0:9.0f} ticks")
+def rep(name, m):
+    if m.any():
+        print(f"   {name:12s} n={m.sum():4d} start {np.median(ps_[m]-t0):8.0f}  dur med {np.median(pe_[m]-ps_[m]):8.0f} max {np.max(pe_[m]-ps_[m]):8.0f}  end max {np.max(pe_[m])-t0:8.0f}")
+rep("conv", idx < n_conv)
+rep("slab", (idx >= n_conv) & (idx < n_conv + 49))
+rep("small", (idx >= n_conv + 49) & (idx < n_conv + 51))
+rep("rest", (idx >= n_conv + 51) & (idx < idx.max()))
+rep("writeback", idx == idx.max())
