@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PRISM_ABI_VERSION 1
+#define PRISM_ABI_VERSION 2
 
 #define PRISM_OK 0
 #define PRISM_ERR_INVALID (-1)     /* bad argument / shape the kernels do not cover          */
@@ -71,8 +71,8 @@ typedef struct prism_replay_desc {
     uint8_t *flags;      /* [capacity] PRISM_FLAG_*                                           */
     int32_t *link;       /* [capacity] ring slot of the stored successor, -1 if none yet      */
     int32_t *back;       /* [capacity] ring slot of the predecessor that links here, or -1    */
-    float *sum_tree;     /* [2*tree_capacity] or NULL for uniform replay                      */
-    float *min_tree;     /* [2*tree_capacity] or NULL                                         */
+    float *tree;         /* [2*tree_capacity][2] {sum, min} of every node interleaved (both children
+                            of a node are one aligned 16-byte load); NULL for uniform replay   */
     float *per_state;    /* [4] {running max raw priority, last p_sum, last p_min, unused}    */
     int32_t *status;     /* [1] sticky PRISM_STATUS_* bits                                    */
     double gammas[PRISM_MAX_NSTEP + 1]; /* gamma**k as Python float64 (timestep_buffer.py:17)  */
@@ -127,7 +127,7 @@ int prism_per_update(const prism_replay_desc *rp, const int64_t *index, const fl
  * saved sampler, torchrl PrioritizedSampler.loads, or a synthetic pre-fill). */
 int prism_per_rebuild(const prism_replay_desc *rp, prism_stream_t stream);
 
-/* out[0] = sum_tree.query(0,size), out[1] = min_tree.query(0,size) (device floats). */
+/* out[0] = sum.query(0,size), out[1] = min.query(0,size) (device floats). */
 int prism_per_query(const prism_replay_desc *rp, int64_t size, float *out2, prism_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -253,7 +253,7 @@ int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream)
 /* TimestepBuffer.sample (timestep_buffer.py:35-51) fused with the embedding of both observations.
  * Writes the minibatch into ld->obs/next_obs/reward/nonterminal/gamma/action (the static batch),
  * out_index [B] int64 and out_weight [B] (set ld->per_weights = out_weight to use them).
- * rp->sum_tree == NULL selects uniform replay. */
+ * rp->tree == NULL selects uniform replay. */
 int prism_step_front(const prism_learner_desc *ld, const prism_replay_desc *rp, int64_t size,
                      const float *mass, uint64_t seed, uint64_t offset, float beta,
                      int64_t *out_index, float *out_weight, prism_stream_t stream);

@@ -30,7 +30,7 @@ class PrismError(RuntimeError):
 class ReplayDesc(ctypes.Structure):
     _fields_ = [("capacity", c_i64), ("tree_capacity", c_i64), ("obs_elems", c_i32), ("n_step", c_i32),
                 ("obs", c_vp), ("succ_obs", c_vp), ("reward", c_vp), ("action", c_vp), ("flags", c_vp),
-                ("link", c_vp), ("back", c_vp), ("sum_tree", c_vp), ("min_tree", c_vp), ("per_state", c_vp),
+                ("link", c_vp), ("back", c_vp), ("tree", c_vp), ("per_state", c_vp),
                 ("status", c_vp), ("gammas", ctypes.c_double * (PRISM_MAX_NSTEP + 1))]
 
 
@@ -119,7 +119,7 @@ def lib():
             except AttributeError as e:
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
-        if L.prism_abi_version() != 1:
+        if L.prism_abi_version() != 2:
             raise NativeLibraryError("ABI version mismatch between prism_amd and libprism_hip.so")
         _lib = L
     return _lib

@@ -65,7 +65,8 @@ struct IqnWs {           // workspace pointers (device)
     float *slabs;        // [n_chunks][SLAB]
     float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
     float *normpart;     // [NORM_SLOTS]
-    unsigned int *ticket;   // [4] {adam, conv, -, -}, zero-initialised by the caller, self-resetting
+    float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
+    unsigned int *ticket;   // [4] {adam, conv, -, sibling-record state}, zero-initialised by the caller, self-resetting
 };
 
 constexpr int SLAB = E_DIM * K_BASIS + E_DIM + E_DIM + E_DIM + H_DIM * E_DIM;  // phi_w|phi_b|ln1_g|ln1_b|w1
@@ -78,6 +79,7 @@ struct IqnArgs {
     int n_chunks;          // row chunks of the backward
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
+    int conv_in_bwd;       // conv-backward partials are produced by the tail of iqn_bwd_kernel (bwd_conv_ok)
     int head_layers;       // 2: LN-Linear-ReLU-LN-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
@@ -201,7 +203,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 #define PRISM_STAMP(k)                                                                     \
     do {                                                                                   \
-        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -664,6 +666,28 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
 // ------------------------------------------------------------------------------------------
 constexpr int BWD_WAVE_LDS = 16 * CS + 16 * HS;     // floats per wave (cos tile + dpre1 tile)
 constexpr int BWD_ACC = 16 + 32 + 3;                // accumulators reduced across waves
+// conv-backward partials ride along in the tile loop (IQN-only models: d e[b][n] is final per
+// (sample, column) right there).  The lanes that hold one (sample, position) value -- `share` of
+// them: 2 for T = 8, 4 for T >= 16 -- split the input channels; each lane owns all 9 kernel taps
+// of C/share channels in registers.
+constexpr int BWD_CONV_TAPS = 18;                   // taps per lane: 9 * C / share
+constexpr int BWD_CONV_ROW = 96;                    // floats per partial row: 9C taps (C <= 10) + bias
+constexpr int BWD_MAIN_LDS = 4 * BWD_ACC * 64 > 4 * (16 * CS + 16 * HS) ? 4 * BWD_ACC * 64 : 4 * (16 * CS + 16 * HS);
+constexpr int BWD_CONV_PRE4 = 12;                   // float4 registers per lane staging the wave's observation rows
+__host__ __device__ inline int bwd_conv_share(int T) { return T == 4 ? 1 : (T == 8 ? 2 : 4); }
+// samples one wave may own (its observation rows are staged in LDS: 4 image rows x 10 x C floats each)
+__host__ __device__ inline int bwd_conv_spw(int B, int n_chunks) { return (B + 4 * n_chunks - 1) / (4 * n_chunks) + 1; }
+__host__ __device__ inline int bwd_conv_lds_floats(int B, int C, int n_chunks) {
+    return 4 * BWD_CONV_ROW + 4 * bwd_conv_spw(B, n_chunks) * 40 * C;
+}
+__host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propagate_grad, int T, int C, int B,
+                                            int n_chunks) {
+    const int share = bwd_conv_share(T);
+    return use_iqn && n_heads == 0 && propagate_grad && C % share == 0 && 9 * (C / share) <= BWD_CONV_TAPS &&
+           C / share <= 2 && (C / share == 1 || C % 2 == 0) &&      // 1 channel, or an aligned pair, per lane
+           9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE4 * 64 &&
+           (BWD_MAIN_LDS + bwd_conv_lds_floats(B, C, n_chunks)) * 4 <= 76 * 1024;     // two workgroups per CU
+}
 #ifndef BWD_PREFETCH
 #define BWD_PREFETCH 0
 #endif
@@ -671,7 +695,7 @@ constexpr int BWD_ACC = 16 + 32 + 3;                // accumulators reduced acro
 #define BWD_CHUNKS 8
 #endif
 
-__global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
+__global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
@@ -688,6 +712,27 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
     float *cosl = smem + w * BWD_WAVE_LDS;
     float *dpl = cosl + 16 * CS;
     const float *P = a.params;
+    // conv-backward taps of this lane: channels [sub * cpl, (sub + 1) * cpl) x 3 x 3
+    const int C = a.C, y0 = (cs & 3) * 2;
+    const int share = bwd_conv_share(T), cpl = C / share, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
+    const int sub = T == 8 ? (g & 1) : g;
+    float cacc[BWD_CONV_TAPS], cbias = 0.f;
+#pragma unroll
+    for (int i = 0; i < BWD_CONV_TAPS; ++i) cacc[i] = 0.f;
+    // observation rows y0..y0+3 of this wave's samples: requested first thing, parked in LDS (per
+    // wave, no block barrier) right before the tile loop
+    const int ws_lo = (tile_begin * 16) / T, ws_n = n_mine ? (tiles_per_wave * 16) / T : 0;
+    float *s_obs = smem + BWD_MAIN_LDS + 4 * BWD_CONV_ROW + w * (bwd_conv_spw(a.B, a.n_chunks) * 40 * C);
+    float4 pre4[BWD_CONV_PRE4];
+#pragma unroll
+    for (int i = 0; i < BWD_CONV_PRE4; ++i) {
+        pre4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int idx = lane + 64 * i;
+        if (idx < ws_n * 10 * C) {
+            const int s = idx / (10 * C), o4 = idx - s * 10 * C;
+            pre4[i] = reinterpret_cast<const float4 *>(a.obs + ((int64_t)(ws_lo + s) * 100 + y0 * 10) * C)[o4];
+        }
+    }
 
     PRISM_STAMP(8);
     // per-lane constants ------------------------------------------------------------------------
@@ -714,6 +759,11 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
     for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
 
+#pragma unroll
+    for (int i = 0; i < BWD_CONV_PRE4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < ws_n * 10 * C) reinterpret_cast<float4 *>(s_obs)[idx] = pre4[i];
+    }
     PRISM_STAMP(9);
     // operands of one 16-row tile, fetched one tile ahead of the MFMA work (software prefetch: with a
     // single wave per SIMD nothing else hides the L2 latency)
@@ -786,20 +836,24 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
             s_dbphi += dphi;
         }
         // d e[b][n]: sum over the T rows of a sample
+        float dcv = 0.f;          // ReLU-masked d e of (sample, column n) when it is final in this lane
         if (T == 4) {
             a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
         } else if (T == 8) {
             dep += __shfl_xor(dep, 16, 64);
             if ((g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+            dcv = ev > 0.f ? dep : 0.f;
         } else {
             dep += __shfl_xor(dep, 16, 64);
             dep += __shfl_xor(dep, 32, 64);
             de_acc += dep;
             if (((r0 + 16) % T) == 0) {
                 if (g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
+                dcv = ev > 0.f ? de_acc : 0.f;
                 de_acc = 0.f;
             }
         }
+        if (sub == 0) cbias += dcv;
         // dWphi[n-slice][64] += dphi^T (16 cols x 16 rows) . cos (16 rows x 64)   (A = dpp: D layout == A^T layout)
         // dW1[128][n-slice]  += dpre1^T (128 x 16 rows) . X (16 rows x 16 cols)    (B = xv)
         // k-step outer, accumulator inner: consecutive MFMAs never touch the same accumulator
@@ -811,6 +865,28 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
                 accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
+        }
+        // conv taps of (sample bsm, channel cs>>2, output position (y0 + (j>>3), j&7)); LDS reads of
+        // this wave's own earlier writes need no barrier
+        if (n_mine) {
+            const float *src = s_obs + (bsm - ws_lo) * 40 * C + ((j >> 3) * 10 + (j & 7)) * C + sub * cpl;
+            // all reads of a lane issue back to back (no per-tap branches), then the FMAs
+            if (cpl == 2) {
+                float2 ob[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ob[i] = *reinterpret_cast<const float2 *>(src + ((i / 3) * 10 + (i % 3)) * C);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    cacc[i] = fmaf(dcv, ob[i].x, cacc[i]);
+                    cacc[9 + i] = fmaf(dcv, ob[i].y, cacc[9 + i]);
+                }
+            } else {
+                float ob[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ob[i] = src[((i / 3) * 10 + (i % 3)) * C];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cacc[i] = fmaf(dcv, ob[i], cacc[i]);
+            }
         }
     };
 #if BWD_PREFETCH
@@ -884,6 +960,32 @@ __global__ __launch_bounds__(256) void iqn_bwd_kernel(IqnArgs a) {
         }
     }
     PRISM_STAMP(12);
+    if (!n_mine) return;
+    // ---- conv-backward partial row of this block: fold lanes (16 positions, then the lane groups that
+    // hold the same taps for other samples), then the four waves in fixed order
+    float *s_tap = smem + BWD_MAIN_LDS;                  // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
+    constexpr int TS = BWD_CONV_TAPS + 1;
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+        float v = i < BWD_CONV_TAPS ? cacc[i < BWD_CONV_TAPS ? i : 0] : cbias;
+        v += dpp_move<0xB1, 0xF>(0.f, v);                // 16 positions of the row: quad swaps, then row rotates
+        v += dpp_move<0x4E, 0xF>(0.f, v);
+        v += dpp_move<0x124, 0xF>(0.f, v);
+        v += dpp_move<0x128, 0xF>(0.f, v);
+        if (j == 0) s_tap[(w * 4 + g) * TS + i] = v;
+    }
+    __syncthreads();
+    if (tid <= 9 * C) {
+        // output tap o belongs to lane subset so = o / n_mine; for T = 8 lane groups so and so + 2 hold it
+        const int so = tid < 9 * C ? tid / n_mine : 0, i = tid < 9 * C ? tid - so * n_mine : BWD_CONV_TAPS;
+        float t = 0.f;
+        for (int ww = 0; ww < 4; ++ww) {
+            t += s_tap[(ww * 4 + so) * TS + i];
+            if (T == 8) t += s_tap[(ww * 4 + so + 2) * TS + i];
+        }
+        a.ws.convpart[(int64_t)blockIdx.x * BWD_CONV_ROW + tid] = t;
+    }
+    PRISM_STAMP(26);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -916,6 +1018,7 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
+    PRISM_STAMP(22);
     const int per_s = 16 * C * 3;                 // (c, ci, dy) groups per sample
     for (int item = tid; item < ns * per_s; item += 1024) {
         const int s = item / per_s, og = item - s * per_s;
@@ -941,6 +1044,7 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         s_par[item * 3 + 2] = a2;
     }
     __syncthreads();
+    PRISM_STAMP(23);
     const int nk = 9 * C;
     float *out = a.ws.convpart + (int64_t)cb * CONV_ROW;
     for (int o = tid; o < 16 * nk; o += 1024) {   // o = c*9C + ci*9 + dy*3 + dx  ==  (c*3C + ci*3 + dy)*3 + dx
@@ -960,80 +1064,112 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
 //   S[a][h] = sum_{b: act=a} Sb[b][h];  D[a] = sum_{b: act=a} Db[b];  db1[h] = sum_b Pb[b][h]
 //   dW2[a][h] = g2[h] S[a][h] + beta2[h] D[a];  dg2[h] = sum_a W2[a][h] S[a][h];  dbeta2[h] = sum_a W2[a][h] D[a]
 // 1024 threads = 16 units x 64 batch parts.  Slice 0 also writes db2 and the IQN part of the total loss.
+// Latency-shaped: every global operand is requested up front, the 64 batch parts of all A+1
+// per-unit sums are folded in ONE LDS pass (16 reads + a quad reduction per thread), and the tail
+// runs as (action, unit) threads.  `pool`: SMALL_POOL_FLOATS floats of LDS.
 constexpr int SMALL_W = 16;
-__device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq) {
-    __shared__ float s_part[64][SMALL_W];
-    __shared__ float s_S[16][SMALL_W];
+constexpr int SMALL_GROUP = 8;                                   // per-unit sums folded per LDS pass
+constexpr int SMALL_POOL_FLOATS = SMALL_GROUP * 64 * 17;
+__device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq, float *pool) {
+    __shared__ float s_S[17][SMALL_W];      // [A] = b1 row
     __shared__ float s_D[16];
     __shared__ float s_lw[16];
+    __shared__ float s_dgb[2][16][SMALL_W];
     const int tid = threadIdx.x, B = a.B, A = a.A;
     const int hl = tid & (SMALL_W - 1), part = tid >> 4, h = slice * SMALL_W + hl;
-    float sA[16];
+    float *gr = a.grads;
+    const float *P = a.params;
+    // tail operands of thread (action ta, unit hl): requested now, used last
+    const int ta = tid >> 4;
+    float w2 = 0.f, g2 = 0.f, be2 = 0.f;
+    if (ta < A) {
+        w2 = P[a.off.iqn_w2 + ta * H_DIM + h];
+        g2 = P[a.off.iqn_ln2_g + h];
+        be2 = P[a.off.iqn_ln2_b + h];
+    }
+    float sA[16], dA[16];
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
+    for (int aa = 0; aa < 16; ++aa) sA[aa] = dA[aa] = 0.f;
     float pb = 0.f;
+    float lw = (slice == 0 && tid < B) ? a.ws.lossw[tid] : 0.f;
 #pragma unroll 4
     for (int b = part; b < B; b += 64) {
         const float v = a.ws.Sb[(int64_t)b * H_DIM + h];
         pb += a.ws.Pb[(int64_t)b * H_DIM + h];
+        const float dv = hl == 0 ? a.ws.Db[b] : 0.f;            // column 16 of the fold: D[a] partials
         const int ab = (int)a.action[b];
 #pragma unroll
-        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
-    }
-    {   // D[a]: one wave per action; slice 0 also sums the weighted losses
-        const int wv = tid >> 6, lane = tid & 63;
-        float s = 0.f, lw = 0.f;
-        if (wv < A)
-            for (int b = lane; b < B; b += 64) s += ((int)a.action[b] == wv) ? a.ws.Db[b] : 0.f;
-        if (slice == 0)
-            for (int b = tid; b < B; b += 1024) lw += a.ws.lossw[b];
-        s = wave_sum(s);
-        lw = wave_sum(lw);
-        if (lane == 0) {
-            s_D[wv] = s;
-            s_lw[wv] = lw;
+        for (int aa = 0; aa < 16; ++aa) {
+            sA[aa] += (ab == aa) ? v : 0.f;
+            dA[aa] += (ab == aa) ? dv : 0.f;
         }
     }
-    float *gr = a.grads;
-    const float *P = a.params;
+    PRISM_STAMP(16);
+    if (slice == 0) {
+        for (int b = 1024 + tid; b < B; b += 1024) lw += a.ws.lossw[b];
+        lw = wave_sum(lw);
+        if ((tid & 63) == 0) s_lw[tid >> 6] = lw;
+    }
+    PRISM_STAMP(17);
+    // fold the 64 batch parts of sums x = 0..A (x = A is the b1 row), SMALL_GROUP sums per pass;
+    // waves 8..15 fold column 16 (the D[a] partials of each part)
+    for (int x0 = 0; x0 <= A; x0 += SMALL_GROUP) {
+        if (x0) __syncthreads();
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) {
-        if (aa < A) {
-            __syncthreads();
-            s_part[part][hl] = sA[aa];
-            __syncthreads();
-            if (part == 0) {
+        for (int aa = 0; aa < 17; ++aa) {
+            const int x = aa - x0;                               // (aa is compile-time, x0 uniform)
+            if (aa <= A && x >= 0 && x < SMALL_GROUP) {
+                pool[(x * 64 + part) * 17 + hl] = aa == A ? pb : sA[aa < 16 ? aa : 0];
+                if (hl == 0 && aa < A) pool[(x * 64 + part) * 17 + 16] = dA[aa < 16 ? aa : 0];
+            }
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const int x = tid >> 6, rhl = (tid >> 2) & 15, q = tid & 3;
+            if (x0 + x <= A) {
                 float t = 0.f;
-#pragma unroll 16
-                for (int p = 0; p < 64; ++p) t += s_part[p][hl];
-                s_S[aa][hl] = t;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += pool[(x * 64 + q * 16 + i) * 17 + rhl];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                if (q == 0) s_S[x0 + x][rhl] = t;
+            }
+        } else {
+            const int x = (tid - 512) >> 6, lane = tid & 63;
+            if (x0 + x < A) {
+                const float t = wave_sum(pool[(x * 64 + lane) * 17 + 16]);
+                if (lane == 0) s_D[x0 + x] = t;
             }
         }
     }
     __syncthreads();
-    s_part[part][hl] = pb;
+    PRISM_STAMP(18);
+    float dg = 0.f, db = 0.f;
+    if (ta < A) {
+        const float S = s_S[ta][hl], D = s_D[ta];
+        const float dw = g2 * S + be2 * D;
+        gr[a.off.iqn_w2 + ta * H_DIM + h] = dw;
+        sq += dw * dw;
+        dg = w2 * S;
+        db = w2 * D;
+    }
+    if (ta < 16) {
+        s_dgb[0][ta][hl] = dg;
+        s_dgb[1][ta][hl] = db;
+    }
     __syncthreads();
-    if (part == 0) {
+    if (tid < 2 * SMALL_W) {                 // threads [0,16): d ln2_g; [16,32): d ln2_b
+        const int which = tid >> 4;
         float t = 0.f;
-#pragma unroll 16
-        for (int p = 0; p < 64; ++p) t += s_part[p][hl];
+        for (int aa = 0; aa < A; ++aa) t += s_dgb[which][aa][hl];
+        gr[(which ? a.off.iqn_ln2_b : a.off.iqn_ln2_g) + h] = t;
+        sq += t * t;
+    } else if (tid < 3 * SMALL_W) {
+        const float t = s_S[A][hl];
         gr[a.off.iqn_b1 + h] = t;
         sq += t * t;
-        const float g2 = P[a.off.iqn_ln2_g + h], be2 = P[a.off.iqn_ln2_b + h];
-        float dg = 0.f, db = 0.f;
-        for (int aa = 0; aa < A; ++aa) {
-            const float w2 = P[a.off.iqn_w2 + aa * H_DIM + h];
-            const float S = s_S[aa][hl], D = s_D[aa];
-            const float dw = g2 * S + be2 * D;
-            gr[a.off.iqn_w2 + aa * H_DIM + h] = dw;
-            sq += dw * dw;
-            dg += w2 * S;
-            db += w2 * D;
-        }
-        gr[a.off.iqn_ln2_g + h] = dg;
-        gr[a.off.iqn_ln2_b + h] = db;
-        sq += dg * dg + db * db;
     }
+    PRISM_STAMP(19);
     if (slice == 0 && tid < A) {
         const float D = s_D[tid];
         gr[a.off.iqn_b2 + tid] = D;

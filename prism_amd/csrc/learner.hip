@@ -206,8 +206,13 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.lossw = c.f(B);
     w.de_iqn = c.f((size_t)B * E_DIM);
     w.slabs = c.f((size_t)N_CHUNKS * SLAB);
-    w.convpart = c.f((size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW);
+    {
+        const size_t post_rows = (size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW;
+        const size_t bwd_rows = (size_t)(E_DIM / 16) * N_CHUNKS * BWD_CONV_ROW;
+        w.convpart = c.f(post_rows > bwd_rows ? post_rows : bwd_rows);
+    }
     w.normpart = c.f(NORM_SLOTS);
+    w.sib = c.f((size_t)TREE_MAX_LEVELS * B * 2);
     {
         const size_t Hd = d->n_heads, RQ = Hd * (size_t)B;
         w.q_mu1 = c.f(RQ);
@@ -282,6 +287,13 @@ static int check_learner(const prism_learner_desc *ld) {
     return PRISM_OK;
 }
 
+static int post_block_count(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(ld->batch);
+    return post_blocks(ld->batch, d.use_iqn, d.n_heads,
+                       bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS));
+}
+
 static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     const prism_model_dims &d = ld->dims;
     const int B = ld->batch;
@@ -297,6 +309,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
+    a.conv_in_bwd = bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS);
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;
     a.use_iqn = d.use_iqn;
@@ -395,8 +408,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
 
     static bool attr_set = false;
     const size_t fwd_lds = TILE_FWD_LDS_FLOATS * sizeof(float);
-    const size_t bwd_lds = (size_t)(4 * BWD_ACC * 64 > 4 * BWD_WAVE_LDS ? 4 * BWD_ACC * 64 : 4 * BWD_WAVE_LDS) *
-                           sizeof(float);
+    const size_t bwd_lds = (size_t)(BWD_MAIN_LDS + (a.conv_in_bwd ? bwd_conv_lds_floats(B, a.C, N_CHUNKS) : 0)) * sizeof(float);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)iqn_tile_fwd_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
@@ -450,15 +462,16 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     }
     {
         ProfileScope ps_(K_POST, stream);
-        int nb = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(B)
-                                                               : post_blocks(B, ld->dims.use_iqn, ld->dims.n_heads);
+        int nb = post_block_count(ld);
         PostWriteback wb;
         memset(&wb, 0, sizeof(wb));
-        if (ld->fused_replay && ld->fused_replay->sum_tree && ld->fused_index) {
+        if (ld->fused_replay && ld->fused_replay->tree && ld->fused_index) {
             // TD errors are final: the priority writeback rides along as one more block of this launch
             wb.enabled = 1;
             wb.rp = *ld->fused_replay;
             wb.index = ld->fused_index;
+            wb.sib = reinterpret_cast<const float2 *>(a.ws.sib);
+            wb.sib_state = a.ws.ticket + 3;
             wb.alpha = ld->fused_alpha;
             wb.eps = ld->fused_eps;
             wb.block = nb;
@@ -478,8 +491,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
 // grid-norm partial slots valid for the Adam kernels: either what post left, or a fresh pass
 static int prepare_norm(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a, hipStream_t stream) {
     if (ld->hyper.grad_scale == 1.0f) {
-        a.n_slots = ld->dims.head_layers == 1 && ld->dims.n_heads ? post_blocks_dqn1(ld->batch)
-                                                                  : post_blocks(ld->batch, ld->dims.use_iqn, ld->dims.n_heads);
+        a.n_slots = post_block_count(ld);
     } else {
         // data parallel: the gradient was all-reduced after the backward; recompute the partials
         const int nb = 256;
@@ -525,7 +537,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     rc = check_replay_for_step(ld, rp);
     if (rc) return rc;
     PRISM_CHECK_ARG(size > 0 && size <= rp->capacity, "size must be in (0, capacity] (empty storage)");
-    PRISM_CHECK_ARG(out_index && (rp->sum_tree == nullptr || out_weight), "null outputs");
+    PRISM_CHECK_ARG(out_index && (rp->tree == nullptr || out_weight), "null outputs");
     hipStream_t stream = (hipStream_t)stream_;
     IqnArgs a;
     fill_iqn_args(ld, a);
@@ -536,7 +548,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     f.offset = offset;
     f.rng = ld->rng_counters;
     f.beta = beta;
-    f.use_per = rp->sum_tree != nullptr;
+    f.use_per = rp->tree != nullptr;
     f.out_index = out_index;
     f.out_weight = out_weight;
     f.obs = const_cast<float *>(ld->obs);
@@ -576,7 +588,7 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
     k.alpha = alpha;
     k.eps = eps;
     k.take_abs = 1;
-    k.use_per = rp->sum_tree != nullptr && !ld->fused_replay;   // already written back beside the backward pass
+    k.use_per = rp->tree != nullptr && !ld->fused_replay;   // already written back beside the backward pass
     k.rng = ld->rng_counters;
     const int maxT = ld->dims.n_tau > ld->dims.n_tau_next ? ld->dims.n_tau : ld->dims.n_tau_next;
     k.inc_per = (uint64_t)ld->batch;

@@ -9,13 +9,14 @@ static int check_replay(const prism_replay_desc *rp, bool need_tree) {
     int64_t cap = 1;
     while (cap <= rp->capacity) cap <<= 1;
     PRISM_CHECK_ARG(rp->tree_capacity == cap, "tree_capacity must be the smallest power of two > capacity");
+    PRISM_CHECK_ARG(!need_tree || cap <= (1ll << TREE_MAX_LEVELS), "prioritized capacity above 2^26 rows");
     PRISM_CHECK_ARG(rp->obs_elems > 0, "obs_elems");
     PRISM_CHECK_ARG(rp->n_step >= 1 && rp->n_step <= PRISM_MAX_NSTEP, "n_step out of range");
     PRISM_CHECK_ARG(rp->obs && rp->succ_obs && rp->reward && rp->action && rp->flags && rp->link && rp->back,
                     "null ring array");
     PRISM_CHECK_ARG(rp->per_state && rp->status, "null per_state/status");
-    if (need_tree) PRISM_CHECK_ARG(rp->sum_tree && rp->min_tree, "prioritized call on a ring without trees");
-    PRISM_CHECK_ARG((rp->sum_tree == nullptr) == (rp->min_tree == nullptr), "sum/min tree must come together");
+    if (need_tree) PRISM_CHECK_ARG(rp->tree, "prioritized call on a ring without trees");
+    PRISM_CHECK_ARG((reinterpret_cast<uintptr_t>(rp->tree) & 15) == 0, "tree must be 16-byte aligned");
     return PRISM_OK;
 }
 

@@ -16,6 +16,9 @@ namespace prism {
 constexpr int TOP_LEVELS = 11;                 // nodes [1, 2^11) of the sum tree cached in LDS (8 KB)
 constexpr int TOP_NODES = 1 << TOP_LEVELS;
 
+// node n of the interleaved tree: .x = sum, .y = min
+__device__ __forceinline__ float2 *tree_nodes(const prism_replay_desc &rp) { return reinterpret_cast<float2 *>(rp.tree); }
+
 template <bool MIN>
 __device__ __forceinline__ float tree_op(float a, float b) {
     if (MIN) return a < b ? a : b;
@@ -26,10 +29,10 @@ __device__ __forceinline__ float tree_op(float a, float b) {
 // (level, side)) and then folded by one lane in exactly the sequential order.
 // Must be called by all threads of the block; needs blockDim.x >= 128; `scratch` holds 128 floats.
 template <bool MIN>
-__device__ float block_tree_query(const float *__restrict__ v, int64_t cap, int64_t tree_size, int64_t r_in,
+__device__ float block_tree_query(const float2 *__restrict__ v, int64_t cap, int64_t tree_size, int64_t r_in,
                                   float *scratch) {
     const float ident = MIN ? FLT_MAX : 0.0f;
-    if (r_in >= tree_size) return v[1];
+    if (r_in >= tree_size) return MIN ? v[1].y : v[1].x;
     const int t = threadIdx.x;
     if (t < 128) {
         const int level = t >> 1, side = t & 1;
@@ -45,9 +48,9 @@ __device__ float block_tree_query(const float *__restrict__ v, int64_t cap, int6
         }
         if (live && l < r) {
             if (side == 0) {
-                if (l & 1) val = v[l];
+                if (l & 1) val = MIN ? v[l].y : v[l].x;
             } else {
-                if (r & 1) val = v[r - 1];
+                if (r & 1) val = MIN ? v[r - 1].y : v[r - 1].x;
             }
         }
         scratch[t] = val;
@@ -65,11 +68,8 @@ static __global__ void replay_init_kernel(prism_replay_desc rp) {
     const int64_t n = 2 * rp.tree_capacity;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rp.sum_tree) {
-        for (int64_t i = tid; i < n; i += stride) {
-            rp.sum_tree[i] = 0.0f;
-            rp.min_tree[i] = FLT_MAX;
-        }
+    if (rp.tree) {
+        for (int64_t i = tid; i < n; i += stride) tree_nodes(rp)[i] = make_float2(0.0f, FLT_MAX);
     }
     for (int64_t i = tid; i < rp.capacity; i += stride) {
         rp.link[i] = -1;
@@ -85,139 +85,212 @@ static __global__ void replay_init_kernel(prism_replay_desc rp) {
     }
 }
 
-// ---- priority write + ancestor recompute for up to `n` leaves, one workgroup ----------------
+// ---- priority write + ancestor recompute, one workgroup, one leaf per thread ----------------
 // Duplicates: the sequential reference loop leaves the LAST occurrence's value in the leaf, and
-// every ancestor equals op(left, right) of the final children.  We write only the winning
-// occurrence per leaf, then recompute ancestors level-synchronously; threads sharing an ancestor
-// compute the same value from the same finished children, so the races are benign.
-// The lower levels go through global memory (one barrier + L2 round trip each); the top
-// WTOP_LEVELS levels of both trees are recomputed in LDS and written back once.
-constexpr int WTOP_LEVELS = 11;
-constexpr int WTOP = 1 << WTOP_LEVELS;          // nodes [1, WTOP) live in LDS, children up to 2*WTOP
+// every ancestor equals op(left, right) of the final children.
+//
+// Each thread walks its own leaf-to-root path with the running (sum, min) of its current node in
+// registers.  The sibling subtree at every level is either untouched by this batch -- then its
+// value is what global memory held on entry, prefetched for all levels up front -- or it lies on
+// other threads' paths.  To find those without hashing or atomics the leaves are RANKED once
+// (counting sort over LDS on the key (leaf, batch position)): in rank order the nodes of a level
+// are non-decreasing, so the threads sharing a node form a contiguous run [lo, hi) and the
+// sibling's run, if any, starts at `hi` (even node) or ends at `lo` (odd node).  Every thread
+// keeps a 16-byte record {sum, min, lo|hi, leaf} at its rank; one ds_read_b128 of the neighbour
+// record + one ds_write_b128 + one LDS barrier per level.  Threads of a run hold bit-identical
+// state, so any member's record serves.  Global memory is read once and written fire-and-forget.
+// (VALU cost note: a wave64 instruction occupies its SIMD for 4 cycles, so the O(n^2) ranking is
+// kept to one compare + one add-with-carry per key pair.)
+#ifndef TREE_STAMP
+#define TREE_STAMP(k)
+#endif
+constexpr int TREE_MAX_LEVELS = 26;             // tree_capacity <= 2^26 (checked in prism_replay_init)
+constexpr int UPD_MAX = 512;                    // leaves per pass of the single-workgroup writer
+constexpr int UPD_POS_BITS = 9;
+constexpr int TREE_WRITE_LDS_BYTES = UPD_MAX * 8 + UPD_MAX * 4 + 2 * UPD_MAX * 16;
 
-__device__ void block_tree_write(const prism_replay_desc &rp, const int32_t *s_idx, const float *s_val,
-                                 const uint8_t *s_win, int n, float *s_tsum, float *s_tmin) {
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// #keys < me over the slice [j0, j1) of 16-byte groups
+__device__ __forceinline__ uint32_t count_less(const uint32_t *keys, int j0, int j1, uint32_t me) {
+    const uint4 *k4 = reinterpret_cast<const uint4 *>(keys);
+    uint32_t n = 0;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const uint4 k = k4[j];
+        n += (uint32_t)(k.x < me) + (uint32_t)(k.y < me) + (uint32_t)(k.z < me) + (uint32_t)(k.w < me);
+    }
+    return n;
+}
+__device__ __forceinline__ uint32_t count_less(const uint64_t *keys, int j0, int j1, uint64_t me) {
+    const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys);
+    uint32_t n = 0;
+#pragma unroll 4
+    for (int j = 2 * j0; j < 2 * j1; ++j) {
+        const ulonglong2 k = k2[j];
+        n += (uint32_t)(k.x < me) + (uint32_t)(k.y < me);
+    }
+    return n;
+}
+
+// rank of (leaf, tid) among the cnt keys; K = uint32_t while leaf << UPD_POS_BITS fits, else uint64_t
+template <typename K>
+__device__ __forceinline__ int block_rank(int32_t my_idx, int cnt, K *s_key, uint16_t *s_part) {
+    const int tid = threadIdx.x, bd = blockDim.x;
+    const int cnt4 = (cnt + 3) & ~3;
+    if (tid < cnt4) s_key[tid] = tid < cnt ? (((K)(uint32_t)my_idx << UPD_POS_BITS) | (K)tid) : ~(K)0;
+    lds_only_barrier();
+    int cntp = 64;
+    while (cntp < cnt) cntp <<= 1;
+    int parts = bd / cntp;
+    parts = parts > 4 ? 4 : (parts < 1 ? 1 : parts);
+    const int e = tid & (cntp - 1), part = tid / cntp;
+    if (part < parts && e < cnt) {
+        const int n4 = cnt4 >> 2;
+        s_part[part * UPD_MAX + e] = (uint16_t)count_less(s_key, part * n4 / parts, (part + 1) * n4 / parts, s_key[e]);
+    }
+    lds_only_barrier();
+    int rank = 0;
+    if (tid < cnt)
+        for (int q = 0; q < parts; ++q) rank += s_part[q * UPD_MAX + tid];
+    return rank;
+}
+
+// thread t < cnt carries leaf `my_idx` with value `my_val`; among equal leaves the highest t wins.
+// cnt <= min(UPD_MAX, blockDim.x).  `lds`: TREE_WRITE_LDS_BYTES, 16-byte aligned.
+// `sib` (optional): sib[s * sib_stride + t] = {sum, min} of the sibling of thread t's path node at
+// level s as of entry, recorded by whoever walked those paths last (the sampling descent reads
+// both children of every path node anyway); NULL -> prefetch them from the tree here.
+__device__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
+                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+    const int tid = threadIdx.x;
+    const bool active = tid < cnt;
+    int32_t *s_sorted = reinterpret_cast<int32_t *>(lds);               // [UPD_MAX] leaves in rank order
+    float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);        // [UPD_MAX] values in rank order
+    uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials
+    int4 *s_rec = reinterpret_cast<int4 *>(lds + UPD_MAX * 12);         // [2][UPD_MAX]; ranking keys alias it
     const int64_t cap = rp.tree_capacity;
-    const int64_t top = cap < WTOP ? cap : WTOP;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        if (s_win[i]) {
-            const int64_t leaf = (int64_t)s_idx[i] | cap;
-            rp.sum_tree[leaf] = s_val[i];
-            rp.min_tree[leaf] = s_val[i];
+    const int levels = 63 - __clzll((unsigned long long)cap);
+    const int32_t leaf = active ? (int32_t)((int64_t)my_idx | cap) : (int32_t)cap;
+    TREE_STAMP(4);
+    float sib_s[TREE_MAX_LEVELS], sib_m[TREE_MAX_LEVELS];
+#pragma unroll
+    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+        sib_s[s] = 0.f;
+        sib_m[s] = 0.f;
+        if (s < levels && active) {
+            const float2 v = sib ? sib[s * sib_stride + tid] : tree_nodes(rp)[(leaf >> s) ^ 1];
+            sib_s[s] = v.x;
+            sib_m[s] = v.y;
         }
     }
-    __syncthreads();
-    int64_t shift = 1;
-    for (; (cap >> shift) >= top; ++shift) {      // parents still at or below node `top`: via global
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int64_t p = ((int64_t)s_idx[i] | cap) >> shift;
-            const float a = rp.sum_tree[2 * p], b = rp.sum_tree[2 * p + 1];
-            const float c = rp.min_tree[2 * p], d = rp.min_tree[2 * p + 1];
-            rp.sum_tree[p] = a + b;
-            rp.min_tree[p] = c < d ? c : d;
-        }
-        __syncthreads();
+    TREE_STAMP(23);
+    const int rank = levels + UPD_POS_BITS <= 32
+                         ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_rec), s_part)
+                         : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_rec), s_part);
+    TREE_STAMP(25);
+    if (active) {
+        s_sorted[rank] = leaf;
+        s_val[rank] = my_val;
     }
-    // nodes [1, 2*top): the children of the first LDS level were finished above (or are leaves)
-#pragma unroll 8
-    for (int64_t i = threadIdx.x; i < 2 * top; i += blockDim.x) {   // independent loads: keep many in flight
-        s_tsum[i] = rp.sum_tree[i];
-        s_tmin[i] = rp.min_tree[i];
+    lds_only_barrier();
+    TREE_STAMP(26);
+    // my run of equal leaves (almost always just me); its last member is the last occurrence
+    int lo = rank, hi = rank + 1;
+    float cs = 0.f, cm = 0.f;
+    if (active) {
+        while (lo > 0 && s_sorted[lo - 1] == leaf) --lo;
+        while (hi < cnt && s_sorted[hi] == leaf) ++hi;
+        cs = cm = s_val[hi - 1];
     }
-    __syncthreads();
-    const int64_t first_lds_shift = shift;
-    for (; (cap >> shift) >= 1; ++shift) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int64_t p = ((int64_t)s_idx[i] | cap) >> shift;
-            const float a = s_tsum[2 * p], b = s_tsum[2 * p + 1];
-            const float c = s_tmin[2 * p], d = s_tmin[2 * p + 1];
-            s_tsum[p] = a + b;
-            s_tmin[p] = c < d ? c : d;
-        }
-        __syncthreads();
+    lds_only_barrier();                                         // ranking keys (aliasing the records) are dead
+    if (active) {
+        s_rec[rank] = make_int4(__float_as_int(cs), __float_as_int(cm), lo | (hi << 16), leaf);
+        tree_nodes(rp)[leaf] = make_float2(cs, cm);
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        for (int64_t sh = first_lds_shift; (cap >> sh) >= 1; ++sh) {
-            const int64_t p = ((int64_t)s_idx[i] | cap) >> sh;
-            rp.sum_tree[p] = s_tsum[p];
-            rp.min_tree[p] = s_tmin[p];
+    lds_only_barrier();
+    TREE_STAMP(5);
+#pragma unroll
+    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+        if (s < levels) {                                       // uniform
+            const int4 *buf = s_rec + (s & 1) * UPD_MAX;
+            int4 *nbuf = s_rec + ((s + 1) & 1) * UPD_MAX;
+            if (active) {
+                const int32_t child = leaf >> s;
+                const bool odd = child & 1;
+                const int j = odd ? lo - 1 : hi;
+                float os = sib_s[s], om = sib_m[s];
+                if (odd ? lo > 0 : hi < cnt) {
+                    const int4 q = buf[j];
+                    if ((q.w >> s) == (child ^ 1)) {            // the neighbouring run is my sibling
+                        os = __int_as_float(q.x);
+                        om = __int_as_float(q.y);
+                        lo = min(lo, q.z & 0xffff);
+                        hi = max(hi, q.z >> 16);
+                    }
+                }
+                const float ls = odd ? os : cs, rs = odd ? cs : os;
+                const float lm = odd ? om : cm, rm = odd ? cm : om;
+                cs = ls + rs;
+                cm = lm < rm ? lm : rm;
+                tree_nodes(rp)[leaf >> (s + 1)] = make_float2(cs, cm);
+                nbuf[rank] = make_int4(__float_as_int(cs), __float_as_int(cm), lo | (hi << 16), leaf);
+            }
+            lds_only_barrier();
+            TREE_STAMP(6 + s);
         }
     }
 }
 
-constexpr int UPD_MAX = 1024;  // leaves per pass of the single-workgroup writer
-constexpr int HT_BITS = 11, HT_SIZE = 1 << HT_BITS;   // duplicate-detection hash table (load factor <= 0.5)
-
 // whole PrioritizedSampler.update_priority for one batch, executed by ONE workgroup (any size)
 // `lds`: PER_UPDATE_LDS_BYTES of 16-byte aligned LDS supplied by the calling kernel (so that kernels
 // hosting this routine as one role among others can alias it with their own scratch).
-constexpr int PER_UPDATE_LDS_BYTES = UPD_MAX * 4 + UPD_MAX * 4 + UPD_MAX + 64 + 2 * (2 * WTOP) * 4 + 2 * HT_SIZE * 4;
+constexpr int PER_UPDATE_LDS_BYTES = TREE_WRITE_LDS_BYTES + 128;
 __device__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
-                                 char *lds) {
-    int32_t *s_idx = reinterpret_cast<int32_t *>(lds);
-    float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);
-    float *s_red = reinterpret_cast<float *>(lds + UPD_MAX * 8);
-    float *s_tsum = s_red + 16, *s_tmin = s_tsum + 2 * WTOP;
-    int32_t *s_hkey = reinterpret_cast<int32_t *>(s_tmin + 2 * WTOP), *s_hpos = s_hkey + HT_SIZE;
-    uint8_t *s_win = reinterpret_cast<uint8_t *>(s_hpos + HT_SIZE);
+                                 char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+    float *s_red = reinterpret_cast<float *>(lds + TREE_WRITE_LDS_BYTES);
+    const int tid = threadIdx.x;
+    const int pass = min(UPD_MAX, (int)blockDim.x);
+    TREE_STAMP(0);
+    // first pass's operands and the running max get in flight together
+    const float old_max = tid == 0 ? rp.per_state[0] : 0.f;
+    int32_t me = 0;
+    float p0 = 0.f;
+    if (tid < min(pass, n)) {
+        p0 = priority[tid];
+        if (take_abs) p0 = fabsf(p0);
+        me = (int32_t)index[tid];
+    }
     // running max of the raw priorities (torchrl tracks it before the +eps, **alpha)
-    float m = -FLT_MAX;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float m = tid < min(pass, n) ? p0 : -FLT_MAX;
+    for (int i = pass + tid; i < n; i += blockDim.x) {
         float p = priority[i];
         if (take_abs) p = fabsf(p);
         m = fmaxf(m, p);
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float mm = rp.per_state[0];
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, s_red[w]);
-        rp.per_state[0] = mm;
-    }
-    for (int base = 0; base < n; base += UPD_MAX) {
-        const int cnt = min(UPD_MAX, n - base);
-        __syncthreads();
-        const int cnt4 = (cnt + 3) & ~3;
-        for (int i = threadIdx.x; i < cnt4; i += blockDim.x) {
-            if (i < cnt) {
-                float p = priority[base + i];
-                if (take_abs) p = fabsf(p);
-                s_idx[i] = (int32_t)index[base + i];
-                s_val[i] = pow_alpha(p + eps, alpha);
-            } else {
-                s_idx[i] = -1;
+    if ((tid & 63) == 0) s_red[tid >> 6] = m;
+    TREE_STAMP(1);
+    for (int base = 0; base < n; base += pass) {
+        const int cnt = min(pass, n - base);
+        float val = 0.f;
+        if (base) {
+            __syncthreads();                                    // previous pass: stores drained, LDS free
+            if (tid < cnt) {
+                p0 = priority[base + tid];
+                if (take_abs) p0 = fabsf(p0);
+                me = (int32_t)index[base + tid];
             }
         }
-        __syncthreads();
-        // last occurrence wins: LDS hash table keyed by leaf, value = highest batch position seen
-        for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) {
-            s_hkey[i] = -1;
-            s_hpos[i] = -1;
+        if (tid < cnt) val = pow_alpha(p0 + eps, alpha);
+        TREE_STAMP(3);
+        block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride);   // a record is only
+        if (base == 0 && tid == 0) {                                                       // valid for one pass
+            float mm = old_max;                                 // (s_red was published before the first barrier)
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, s_red[w]);
+            rp.per_state[0] = mm;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const int32_t me = s_idx[i];
-            uint32_t slot = ((uint32_t)me * 2654435761u) >> (32 - HT_BITS);
-            for (;;) {
-                const int32_t prev = atomicCAS(&s_hkey[slot], -1, me);
-                if (prev == -1 || prev == me) {
-                    atomicMax(&s_hpos[slot], i);
-                    break;
-                }
-                slot = (slot + 1) & (HT_SIZE - 1);
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const int32_t me = s_idx[i];
-            uint32_t slot = ((uint32_t)me * 2654435761u) >> (32 - HT_BITS);
-            while (s_hkey[slot] != me) slot = (slot + 1) & (HT_SIZE - 1);
-            s_win[i] = (s_hpos[slot] == i);
-        }
-        __syncthreads();
-        block_tree_write(rp, s_idx, s_val, s_win, cnt, s_tsum, s_tmin);
     }
 }
 
@@ -262,10 +335,7 @@ static __global__ __launch_bounds__(1024) void replay_link_kernel(prism_replay_d
                                                           const int32_t *__restrict__ slots,
                                                           const int32_t *__restrict__ prev_slot, float alpha,
                                                           float eps) {
-    __shared__ __attribute__((aligned(16))) int32_t s_idx[UPD_MAX];
-    __shared__ float s_val[UPD_MAX];
-    __shared__ uint8_t s_win[UPD_MAX];
-    __shared__ float s_tsum[2 * WTOP], s_tmin[2 * WTOP];
+    __shared__ __attribute__((aligned(16))) char s_pool[TREE_WRITE_LDS_BYTES];
     if (threadIdx.x == 0) {
         for (int i = 0; i < n; ++i) {
             const int32_t s = slots[i];
@@ -282,18 +352,14 @@ static __global__ __launch_bounds__(1024) void replay_link_kernel(prism_replay_d
             }
         }
     }
-    if (!rp.sum_tree) return;
+    if (!rp.tree) return;
     const float prio = pow_alpha(rp.per_state[0] + eps, alpha);
-    for (int base = 0; base < n; base += UPD_MAX) {
-        const int cnt = min(UPD_MAX, n - base);
+    const int pass = min(UPD_MAX, (int)blockDim.x);
+    for (int base = 0; base < n; base += pass) {
+        const int cnt = min(pass, n - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            s_idx[i] = (int32_t)slots[base + i];
-            s_val[i] = prio;
-            s_win[i] = 1;
-        }
-        __syncthreads();
-        block_tree_write(rp, s_idx, s_val, s_win, cnt, s_tsum, s_tmin);
+        const int32_t me = (int)threadIdx.x < cnt ? (int32_t)slots[base + threadIdx.x] : 0;
+        block_tree_write(rp, me, prio, cnt, s_pool);
     }
 }
 
@@ -302,10 +368,8 @@ static __global__ void per_rebuild_level_kernel(prism_replay_desc rp, int64_t fi
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const int64_t p = first + i;
-        const float a = rp.sum_tree[2 * p], b = rp.sum_tree[2 * p + 1];
-        const float c = rp.min_tree[2 * p], d = rp.min_tree[2 * p + 1];
-        rp.sum_tree[p] = a + b;
-        rp.min_tree[p] = c < d ? c : d;
+        const float4 ch = reinterpret_cast<const float4 *>(rp.tree)[p];     // {left.sum, left.min, right.sum, right.min}
+        tree_nodes(rp)[p] = make_float2(ch.x + ch.z, ch.y < ch.w ? ch.y : ch.w);
     }
 }
 
@@ -318,11 +382,37 @@ __device__ __forceinline__ int64_t tree_descend(const prism_replay_desc &rp, con
     float v = mass;
     while (node < cap) {
         node <<= 1;
-        const float lv = node < top ? s_top[node] : rp.sum_tree[node];
+        const float lv = node < top ? s_top[node] : tree_nodes(rp)[node].x;
         if (v > lv) {
             v -= lv;
             node |= 1;
         }
+    }
+    return node ^ cap;
+}
+
+// The same descent over the interleaved tree with a float2 LDS top, which also records for every
+// level s (0 = leaf level) {sum, min} of the sibling of the node it steps into: sib[s * stride].
+__device__ __forceinline__ int64_t tree_descend_record(const prism_replay_desc &rp, const float2 *s_top, int64_t top,
+                                                       float mass, float2 *sib, int stride, float *leaf_sum) {
+    const int64_t cap = rp.tree_capacity;
+    if (mass > s_top[1].x) return rp.capacity;
+    int64_t node = 1;
+    float v = mass;
+    int s = 63 - __clzll((unsigned long long)cap);
+    while (node < cap) {
+        node <<= 1;
+        --s;
+        // {left.sum, left.min, right.sum, right.min}: one aligned 16-byte load
+        const float4 ch = node < top ? *reinterpret_cast<const float4 *>(&s_top[node])
+                                     : reinterpret_cast<const float4 *>(rp.tree)[node >> 1];
+        const bool right = v > ch.x;
+        if (right) {
+            v -= ch.x;
+            node |= 1;
+        }
+        sib[(int64_t)s * stride] = right ? make_float2(ch.x, ch.y) : make_float2(ch.z, ch.w);
+        *leaf_sum = right ? ch.z : ch.x;
     }
     return node ^ cap;
 }
@@ -371,9 +461,9 @@ static __global__ __launch_bounds__(256) void per_sample_kernel(prism_replay_des
     const int64_t cap = rp.tree_capacity;
     const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;   // nodes [1, top) are internal or leaves of a tiny tree
 #pragma unroll 8
-    for (int i = threadIdx.x; i < top; i += blockDim.x) s_top[i] = rp.sum_tree[i];
-    const float p_sum = block_tree_query<false>(rp.sum_tree, cap, rp.capacity, size, s_scratch);
-    const float p_min = block_tree_query<true>(rp.min_tree, cap, rp.capacity, size, s_scratch);
+    for (int i = threadIdx.x; i < top; i += blockDim.x) s_top[i] = tree_nodes(rp)[i].x;
+    const float p_sum = block_tree_query<false>(tree_nodes(rp), cap, rp.capacity, size, s_scratch);
+    const float p_min = block_tree_query<true>(tree_nodes(rp), cap, rp.capacity, size, s_scratch);
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         rp.per_state[1] = p_sum;
@@ -397,14 +487,14 @@ static __global__ __launch_bounds__(256) void per_sample_kernel(prism_replay_des
     int64_t idx = tree_descend(rp, s_top, top, mass);
     if (idx > size - 1) idx = size - 1;
     out_index[i] = idx;
-    const float leaf = rp.sum_tree[idx | cap];
+    const float leaf = tree_nodes(rp)[idx | cap].x;
     out_weight[i] = pow_neg_beta(leaf / p_min, beta);
 }
 
 static __global__ void per_query_kernel(prism_replay_desc rp, int64_t size, float *out2) {
     __shared__ float s_scratch[128];
-    const float p_sum = block_tree_query<false>(rp.sum_tree, rp.tree_capacity, rp.capacity, size, s_scratch);
-    const float p_min = block_tree_query<true>(rp.min_tree, rp.tree_capacity, rp.capacity, size, s_scratch);
+    const float p_sum = block_tree_query<false>(tree_nodes(rp), rp.tree_capacity, rp.capacity, size, s_scratch);
+    const float p_min = block_tree_query<true>(tree_nodes(rp), rp.tree_capacity, rp.capacity, size, s_scratch);
     if (threadIdx.x == 0) {
         out2[0] = p_sum;
         out2[1] = p_min;

@@ -86,7 +86,7 @@ struct FrontArgs {
 // observations;  blocks [B, B + H/4): u = W1 g1, v = W1 beta1;  then PACK_BLOCKS (x2 with a target
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
 __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
-    __shared__ float s_top[TOP_NODES];
+    __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ float s_scratch[128];
     __shared__ float s_obs[2][1000];
     __shared__ float s_w[2][16 * 10 * 9];
@@ -116,9 +116,9 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         const int64_t cap = rp.tree_capacity;
         const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
 #pragma unroll 8
-        for (int i = tid; i < top; i += 256) s_top[i] = rp.sum_tree[i];
-        const float p_sum = block_tree_query<false>(rp.sum_tree, cap, rp.capacity, f.size, s_scratch);
-        const float p_min = block_tree_query<true>(rp.min_tree, cap, rp.capacity, f.size, s_scratch);
+        for (int i = tid; i < top; i += 256) s_top[i] = tree_nodes(rp)[i];
+        const float p_sum = block_tree_query<false>(tree_nodes(rp), cap, rp.capacity, f.size, s_scratch);
+        const float p_min = block_tree_query<true>(tree_nodes(rp), cap, rp.capacity, f.size, s_scratch);
         __syncthreads();
         if (tid == 0) {
             if (b == 0) {
@@ -138,10 +138,19 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
                 ph(f.offset + (f.rng ? f.rng[0] : 0ull) + (uint64_t)b, 0x5045524dull, r);
                 mass = (float)(0.0 + ((double)p_sum - 0.0) * u64_to_unit_double(r[0], r[1]));
             }
-            idx = tree_descend(rp, s_top, top, mass);
-            if (idx > f.size - 1) idx = f.size - 1;
+            // the descent reads both children of every path node; the one it does not step into is
+            // exactly what the priority writeback needs later -> record it, level-major
+            float leaf_sum = 0.f;
+            idx = tree_descend_record(rp, s_top, top, mass, reinterpret_cast<float2 *>(a.ws.sib) + b, B, &leaf_sum);
+            unsigned int rec = 1u;                                  // 1 = record valid, 2 = not usable
+            if (idx > f.size - 1) {
+                idx = f.size - 1;
+                leaf_sum = tree_nodes(rp)[idx | cap].x;
+                rec = 2u;
+            }
+            if (b == 0 || rec == 2u) atomicMax(a.ws.ticket + 3, rec);
             f.out_index[b] = idx;
-            f.out_weight[b] = pow_neg_beta(rp.sum_tree[idx | cap] / p_min, f.beta);
+            f.out_weight[b] = pow_neg_beta(leaf_sum / p_min, f.beta);
             s_i64[0] = idx;
         }
     } else if (tid == 0) {
@@ -191,8 +200,8 @@ constexpr int POST_SMALL_BLOCKS = H_DIM / SMALL_W;           // 8 (IQN small ten
 constexpr int POST_QSMALL_BLOCKS = H_DIM / 64;               // 2 per head
 
 __host__ __device__ inline int post_q_slab_blocks(int n_heads) { return (n_heads * (Q_SLAB / 4) + 1023) / 1024; }
-__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads) {
-    int n = (B + CONV_SPB - 1) / CONV_SPB;
+__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd) {
+    int n = conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
     if (use_iqn) n += POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
     if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_QSMALL_BLOCKS;
     return n;
@@ -218,6 +227,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
 struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as the last block of the post launch
     prism_replay_desc rp;
     const int64_t *index;
+    const float2 *sib;        // sibling record of the front kernel's descents ([level][B])
+    unsigned int *sib_state;  // 0 = none, 1 = valid for `index`, 2 = unusable (a sample was clamped); consumed here
     float alpha, eps;
     int enabled, block;
 };
@@ -226,23 +237,43 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
     constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
                                                                                        : (int)(CONV_LDS_FLOATS * sizeof(float));
+    static_assert(POOL >= (int)(SMALL_POOL_FLOATS * sizeof(float)), "small-tensor fold must fit the pool");
     __shared__ __attribute__((aligned(16))) char s_pool[POOL];
     __shared__ float s_red[64];
     PRISM_STAMP(13);
     if (wb.enabled && (int)blockIdx.x == wb.block) {
-        per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool);
+        const unsigned int rec = wb.sib_state ? *wb.sib_state : 0u;
+        per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, rec == 1u ? wb.sib : nullptr,
+                         a.B);
+        if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;      // (every thread read it before its first barrier)
         PRISM_STAMP(14);
         return;
     }
     __shared__ float s_kappa[Q_MAX_HEADS];
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
-    const int n_conv = (B + CONV_SPB - 1) / CONV_SPB;
+    const int n_conv = a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
     int blk = blockIdx.x;
     float sq = 0.f;
-    if (blk < n_conv) {
+    if (a.conv_in_bwd && blk == 0) {
+        // the backward kernel left one partial row per (row chunk rc, column slice cs): channel c owns
+        // slices 4c..4c+3.  Fold them in fixed order (rc outer, slice inner).
+        const int nk = 9 * C, n_out = 16 * nk + 16, n_cs = E_DIM / 16;
+        for (int o = tid; o < n_out; o += 1024) {
+            const int c = o < 16 * nk ? o / nk : o - 16 * nk, k = o < 16 * nk ? o - c * nk : nk;
+            const float *src = a.ws.convpart + (int64_t)(4 * c) * BWD_CONV_ROW + k;
+            float t = 0.f;
+            for (int rc = 0; rc < a.n_chunks; ++rc) {
+                const float *r = src + (int64_t)rc * n_cs * BWD_CONV_ROW;
+                t += ((r[0] + r[BWD_CONV_ROW]) + r[2 * BWD_CONV_ROW]) + r[3 * BWD_CONV_ROW];
+            }
+            a.grads[(o < 16 * nk ? a.off.conv_w : a.off.conv_b - 16 * nk) + o] = t;
+            sq += t * t;
+        }
+    } else if (blk < n_conv) {
         __shared__ int s_last;
         conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
+        PRISM_STAMP(20);
         // publish, then let the last arriver fold all partial rows: ONE lane releases after the
         // block's stores have drained (the barrier waits for them), ONE lane acquires
         __syncthreads();
@@ -256,6 +287,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             }
         }
         __syncthreads();
+        PRISM_STAMP(21);
         if (s_last) {
             // fold all partial rows: item = (output, half of the rows), combined through LDS
             const int nk = 9 * C, n_out = 16 * nk + 16;
@@ -303,7 +335,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 }
                 done = true;
             } else if (blk < POST_SLAB_BLOCKS + POST_SMALL_BLOCKS) {
-                small_tensor_block(a, blk - POST_SLAB_BLOCKS, sq);
+                small_tensor_block(a, blk - POST_SLAB_BLOCKS, sq, reinterpret_cast<float *>(s_pool));
                 done = true;
             } else {
                 blk -= POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;

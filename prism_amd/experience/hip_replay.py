@@ -5,7 +5,7 @@ buffer it wraps (``prism/factory/exp_buffer_factory.py:22-33``).
 Data layout (all device memory, allocated once, sized for 288 GB of HBM3E):
     obs, succ_obs  fp32 [capacity, O]     reward fp32 [capacity]      action int32 [capacity]
     flags uint8 [capacity]                link/back int32 [capacity]
-    sum_tree, min_tree fp32 [2 * tree_capacity]
+    tree fp32 [2 * tree_capacity][2]  ({sum, min} per node; sum_tree / min_tree are views)
 Python ``Timestep`` objects are consumed at ``extend()`` and not kept.  ``sample()`` runs two
 kernels (tree descent + IS weights; n-step walk + row gather) and returns the reference's static
 batch layout without any host loop or H2D copy.
@@ -107,15 +107,16 @@ class HipReplayBuffer:
         self.link = torch.full((cap,), -1, dtype=torch.int32, device=dev)
         self.back = torch.full((cap,), -1, dtype=torch.int32, device=dev)
         if self.use_per:
-            self.sum_tree = torch.zeros(2 * self.tree_capacity, dtype=torch.float32, device=dev)
-            self.min_tree = torch.zeros(2 * self.tree_capacity, dtype=torch.float32, device=dev)
+            # {sum, min} of a node side by side: one 16-byte load yields both children of a node
+            self.tree = torch.zeros(2 * self.tree_capacity, 2, dtype=torch.float32, device=dev)
+            self.sum_tree, self.min_tree = self.tree[:, 0], self.tree[:, 1]      # strided views
         else:
-            self.sum_tree = self.min_tree = None
+            self.tree = self.sum_tree = self.min_tree = None
         self.per_state = torch.zeros(4, dtype=torch.float32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         d = N.ReplayDesc()
         d.capacity, d.tree_capacity, d.obs_elems, d.n_step = cap, self.tree_capacity, O, self.n_step
-        for name in ("obs", "succ_obs", "reward", "action", "flags", "link", "back", "sum_tree", "min_tree",
+        for name in ("obs", "succ_obs", "reward", "action", "flags", "link", "back", "tree",
                      "per_state", "status"):
             t = getattr(self, name)
             setattr(d, name, t.data_ptr() if t is not None else None)

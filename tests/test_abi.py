@@ -33,13 +33,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(raw, n), f"{n} declared in prism_hip.h but not exported"
         assert n in N.SIGNATURES, f"{n} has no ctypes signature in prism_amd/_native.py"
     assert set(N.SIGNATURES) == set(names)
-    assert lib.prism_abi_version() == 1
+    assert lib.prism_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     """ctypes mirrors must have the C sizes (guards against silent field drift)."""
     from prism_amd import _native as N
-    assert ctypes.sizeof(N.ReplayDesc) == 8 + 8 + 4 + 4 + 11 * 8 + 16 * 8
+    assert ctypes.sizeof(N.ReplayDesc) == 8 + 8 + 4 + 4 + 10 * 8 + 16 * 8
     assert ctypes.sizeof(N.ModelDims) == 16 * 4 + 4 * 4
     assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
     assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4

@@ -14,12 +14,12 @@ with contextlib.redirect_stdout(io.StringIO()):
 fill_replay(ln.experience_buffer, 20000 if cfg.experience_replay_capacity > 20000 else cfg.experience_replay_capacity, seed=0)
 ag = ln.agent
 for _ in range(5): ln.step(eager=True)
-st = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda:0")
+st = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda:0")
 ag._desc.dbg_stamps = st.data_ptr()
 # tile_fwd and bwd share the stamp buffer: run one step, read after each kernel is impossible -> use
 # the fact that bwd overwrites slots 0..4 of its own blocks; dump both by running twice with masks
 def run():
-    st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 16)
+    st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 32)
 s = run()
 f = s[:256, :8].astype(np.float64)
 names = ["wphi issue+row setup", "cos+barrier", "phi mfma+ytile", "w1 issue+barrier", "layernorm", "trunk mfma", "fold", "ln128+head"]
@@ -33,10 +33,12 @@ print(f"bwd ({nb} workgroups):")
 for k, name in enumerate(["consts", "tile loop", "barrier", "reduce+write"]):
     print(f"   {name:24s} {np.median(b[:, k + 1] - b[:, k]):9.0f}")
 print(f"   total {np.median(b[:, 4] - b[:, 0]):9.0f}   start spread {b[:, 0].max() - b[:, 0].min():9.0f}  end spread {b[:, 4].max() - b[:, 4].min():9.0f}")
+bt = s[:nb, [12, 26]].astype(np.float64)
+if bt[:, 1].any(): print("   conv tail:", int(np.median(bt[:, 1] - bt[:, 0])))
 
 # post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
 B = cfg.batch_size
-n_conv = (B + 3) // 4
+n_conv = 1 if (cfg.use_iqn and not cfg.use_ids and not cfg.use_dqn) else (B + 3) // 4
 pb = s[:, 13] != 0
 ps_, pe_ = s[pb, 13].astype(np.float64), s[pb, 14].astype(np.float64)
 idx = np.nonzero(pb)[0]
@@ -47,6 +49,11 @@ def rep(name, m):
         print(f"   {name:12s} n={m.sum():4d} start {np.median(ps_[m]-t0):8.0f}  dur med {np.median(pe_[m]-ps_[m]):8.0f} max {np.max(pe_[m]-ps_[m]):8.0f}  end max {np.max(pe_[m])-t0:8.0f}")
 rep("conv", idx < n_conv)
 rep("slab", (idx >= n_conv) & (idx < n_conv + 49))
-rep("small", (idx >= n_conv + 49) & (idx < n_conv + 51))
-rep("rest", (idx >= n_conv + 51) & (idx < idx.max()))
+rep("small", (idx >= n_conv + 49) & (idx < n_conv + 57))
+rep("rest", (idx >= n_conv + 57) & (idx < idx.max()))
+sm = s[n_conv + 49:n_conv + 57].astype(np.float64)
+cv = s[:n_conv].astype(np.float64)
+if n_conv > 1: print("   conv phases (partials | publish+ticket | rest): med", [int(np.median(x)) for x in (cv[:, 20] - cv[:, 13], cv[:, 21] - cv[:, 20], cv[:, 14] - cv[:, 21])], "max", [int(np.max(x)) for x in (cv[:, 20] - cv[:, 13], cv[:, 21] - cv[:, 20], cv[:, 14] - cv[:, 21])])
+if n_conv > 1: print("   conv partials (stage | mac | reduce): med", [int(np.median(x)) for x in (cv[:, 22] - cv[:, 13], cv[:, 23] - cv[:, 22], cv[:, 20] - cv[:, 23])])
+print("   small phases (load | D | action rounds | b1+W2 tail | end):", [int(np.median(sm[:, 16 + k] - (sm[:, 13] if k == 0 else sm[:, 15 + k]))) for k in range(4)], int(np.median(sm[:, 14] - sm[:, 19])))
 rep("writeback", idx == idx.max())
