@@ -66,6 +66,7 @@ struct IqnWs {           // workspace pointers (device)
     float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
     float *normpart;     // [NORM_SLOTS]
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
+    float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
     unsigned int *ticket;   // [4] {adam, conv, -, sibling-record state}, zero-initialised by the caller, self-resetting
 };
 

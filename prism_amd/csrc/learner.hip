@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) { clip_adam_
 __global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay_desc rp, BackArgs k) {
     if (blockIdx.x == 0) {
         __shared__ __attribute__((aligned(16))) char s_pool[PER_UPDATE_LDS_BYTES];
-        if (k.use_per) per_update_block(rp, k.index, k.priority, k.n, k.alpha, k.eps, k.take_abs, s_pool);
+        if (k.plan) per_update_finish(rp, k.plan, k.n, s_pool, k.sib, k.n, k.sib_state);
+        else if (k.use_per) per_update_block(rp, k.index, k.priority, k.n, k.alpha, k.eps, k.take_abs, s_pool);
         if (k.rng && threadIdx.x == 0) {
             k.rng[0] += k.inc_per;
             k.rng[1] += k.inc_tau;
@@ -213,6 +214,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     }
     w.normpart = c.f(NORM_SLOTS);
     w.sib = c.f((size_t)TREE_MAX_LEVELS * B * 2);
+    w.wb_plan = c.f((size_t)B * 4);
     {
         const size_t Hd = d->n_heads, RQ = Hd * (size_t)B;
         w.q_mu1 = c.f(RQ);
@@ -286,6 +288,10 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
     return PRISM_OK;
 }
+
+// fused writeback in two halves: preparation beside the gradient reduction (post launch), level walk
+// beside clip + Adam (back launch, 256-thread workgroups: one leaf per thread)
+static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 256; }
 
 static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
@@ -472,12 +478,14 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
             wb.index = ld->fused_index;
             wb.sib = reinterpret_cast<const float2 *>(a.ws.sib);
             wb.sib_state = a.ws.ticket + 3;
+            wb.plan = split_writeback(ld) ? reinterpret_cast<int4 *>(a.ws.wb_plan) : nullptr;
             wb.alpha = ld->fused_alpha;
             wb.eps = ld->fused_eps;
             wb.block = nb;
             nb += 1;
         }
-        hipLaunchKernelGGL(iqn_post_kernel, dim3(nb), dim3(1024), 0, stream, a, wb);
+        if (wb.plan) hipLaunchKernelGGL(iqn_post_kernel<false>, dim3(nb), dim3(1024), 0, stream, a, wb);
+        else hipLaunchKernelGGL(iqn_post_kernel<true>, dim3(nb), dim3(1024), 0, stream, a, wb);
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dbg_z) {
@@ -589,6 +597,14 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
     k.eps = eps;
     k.take_abs = 1;
     k.use_per = rp->tree != nullptr && !ld->fused_replay;   // already written back beside the backward pass
+    k.plan = nullptr;
+    k.sib = nullptr;
+    k.sib_state = nullptr;
+    if (ld->fused_replay && ld->fused_replay->tree && ld->fused_index && split_writeback(ld)) {
+        k.plan = reinterpret_cast<const int4 *>(ws.wb_plan);
+        k.sib = reinterpret_cast<const float2 *>(ws.sib);
+        k.sib_state = ws.ticket + 3;
+    }
     k.rng = ld->rng_counters;
     const int maxT = ld->dims.n_tau > ld->dims.n_tau_next ? ld->dims.n_tau : ld->dims.n_tau_next;
     k.inc_per = (uint64_t)ld->batch;

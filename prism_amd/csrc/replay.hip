@@ -9,7 +9,7 @@ static int check_replay(const prism_replay_desc *rp, bool need_tree) {
     int64_t cap = 1;
     while (cap <= rp->capacity) cap <<= 1;
     PRISM_CHECK_ARG(rp->tree_capacity == cap, "tree_capacity must be the smallest power of two > capacity");
-    PRISM_CHECK_ARG(!need_tree || cap <= (1ll << TREE_MAX_LEVELS), "prioritized capacity above 2^26 rows");
+    PRISM_CHECK_ARG(!need_tree || cap <= (1ll << TREE_MAX_LEVELS), "prioritized capacity above 2^24 - 1 rows");
     PRISM_CHECK_ARG(rp->obs_elems > 0, "obs_elems");
     PRISM_CHECK_ARG(rp->n_step >= 1 && rp->n_step <= PRISM_MAX_NSTEP, "n_step out of range");
     PRISM_CHECK_ARG(rp->obs && rp->succ_obs && rp->reward && rp->action && rp->flags && rp->link && rp->back,

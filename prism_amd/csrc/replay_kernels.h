@@ -104,7 +104,7 @@ static __global__ void replay_init_kernel(prism_replay_desc rp) {
 #ifndef TREE_STAMP
 #define TREE_STAMP(k)
 #endif
-constexpr int TREE_MAX_LEVELS = 26;             // tree_capacity <= 2^26 (checked in prism_replay_init)
+constexpr int TREE_MAX_LEVELS = 24;             // tree_capacity <= 2^24 (checked in prism_replay_init)
 constexpr int UPD_MAX = 512;                    // leaves per pass of the single-workgroup writer
 constexpr int UPD_POS_BITS = 9;
 constexpr int TREE_WRITE_LDS_BYTES = UPD_MAX * 8 + UPD_MAX * 4 + 2 * UPD_MAX * 16;
@@ -156,54 +156,76 @@ __device__ __forceinline__ int block_rank(int32_t my_idx, int cnt, K *s_key, uin
     return rank;
 }
 
-// thread t < cnt carries leaf `my_idx` with value `my_val`; among equal leaves the highest t wins.
-// cnt <= min(UPD_MAX, blockDim.x).  `lds`: TREE_WRITE_LDS_BYTES, 16-byte aligned.
+// The writer comes in three pieces so that a caller may run them in different kernels:
+//   tree_sib_prefetch   sibling values of a leaf's path for all levels, into registers
+//   tree_write_prepare  ranking, runs of equal leaves, winning value -> TreePrep
+//   tree_write_levels   leaf write + level-by-level ancestor recompute
+// Thread t < cnt carries one leaf; cnt <= min(UPD_MAX, blockDim.x); `lds`: TREE_WRITE_LDS_BYTES.
+struct TreePrep {
+    int rank, lo, hi;      // position in (leaf, batch position) order; run of equal leaves [lo, hi)
+    float val;             // value of the last occurrence of this leaf
+};
+struct SibRegs {
+    float s[TREE_MAX_LEVELS], m[TREE_MAX_LEVELS];
+};
+
 // `sib` (optional): sib[s * sib_stride + t] = {sum, min} of the sibling of thread t's path node at
 // level s as of entry, recorded by whoever walked those paths last (the sampling descent reads
-// both children of every path node anyway); NULL -> prefetch them from the tree here.
-__device__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
-                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+// both children of every path node anyway); NULL -> read them from the tree.
+__device__ __forceinline__ void tree_sib_prefetch(const prism_replay_desc &rp, int32_t leaf, bool active, int levels,
+                                                  const float2 *__restrict__ sib, int sib_stride, SibRegs &r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+        r.s[s] = 0.f;
+        r.m[s] = 0.f;
+        if (s < levels && active) {
+            const float2 v = sib ? sib[s * sib_stride + tid] : tree_nodes(rp)[(leaf >> s) ^ 1];
+            r.s[s] = v.x;
+            r.m[s] = v.y;
+        }
+    }
+}
+
+__device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t leaf, float my_val, int cnt, int levels,
+                                                       char *lds) {
     const int tid = threadIdx.x;
     const bool active = tid < cnt;
     int32_t *s_sorted = reinterpret_cast<int32_t *>(lds);               // [UPD_MAX] leaves in rank order
     float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);        // [UPD_MAX] values in rank order
     uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials
-    int4 *s_rec = reinterpret_cast<int4 *>(lds + UPD_MAX * 12);         // [2][UPD_MAX]; ranking keys alias it
-    const int64_t cap = rp.tree_capacity;
-    const int levels = 63 - __clzll((unsigned long long)cap);
-    const int32_t leaf = active ? (int32_t)((int64_t)my_idx | cap) : (int32_t)cap;
-    TREE_STAMP(4);
-    float sib_s[TREE_MAX_LEVELS], sib_m[TREE_MAX_LEVELS];
-#pragma unroll
-    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
-        sib_s[s] = 0.f;
-        sib_m[s] = 0.f;
-        if (s < levels && active) {
-            const float2 v = sib ? sib[s * sib_stride + tid] : tree_nodes(rp)[(leaf >> s) ^ 1];
-            sib_s[s] = v.x;
-            sib_m[s] = v.y;
-        }
-    }
-    TREE_STAMP(23);
-    const int rank = levels + UPD_POS_BITS <= 32
-                         ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_rec), s_part)
-                         : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_rec), s_part);
+    char *s_keys = lds + UPD_MAX * 12;                                  // ranking keys alias the records
+    TreePrep p;
+    p.rank = levels + UPD_POS_BITS <= 32 ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_keys), s_part)
+                                         : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_keys), s_part);
     TREE_STAMP(25);
     if (active) {
-        s_sorted[rank] = leaf;
-        s_val[rank] = my_val;
+        s_sorted[p.rank] = leaf;
+        s_val[p.rank] = my_val;
     }
     lds_only_barrier();
     TREE_STAMP(26);
     // my run of equal leaves (almost always just me); its last member is the last occurrence
-    int lo = rank, hi = rank + 1;
-    float cs = 0.f, cm = 0.f;
+    p.lo = p.rank;
+    p.hi = p.rank + 1;
+    p.val = 0.f;
     if (active) {
-        while (lo > 0 && s_sorted[lo - 1] == leaf) --lo;
-        while (hi < cnt && s_sorted[hi] == leaf) ++hi;
-        cs = cm = s_val[hi - 1];
+        while (p.lo > 0 && s_sorted[p.lo - 1] == leaf) --p.lo;
+        while (p.hi < cnt && s_sorted[p.hi] == leaf) ++p.hi;
+        p.val = s_val[p.hi - 1];
     }
-    lds_only_barrier();                                         // ranking keys (aliasing the records) are dead
+    lds_only_barrier();                                         // ranking scratch is dead from here
+    return p;
+}
+
+__device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, int32_t leaf, const TreePrep &p, int cnt,
+                                                  int levels, char *lds, const SibRegs &sr) {
+    const int tid = threadIdx.x;
+    const bool active = tid < cnt;
+    int4 *s_rec = reinterpret_cast<int4 *>(lds + UPD_MAX * 12);         // [2][UPD_MAX]
+    const int rank = p.rank;
+    int lo = p.lo, hi = p.hi;
+    float cs = p.val, cm = p.val;
     if (active) {
         s_rec[rank] = make_int4(__float_as_int(cs), __float_as_int(cm), lo | (hi << 16), leaf);
         tree_nodes(rp)[leaf] = make_float2(cs, cm);
@@ -219,7 +241,7 @@ __device__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, fl
                 const int32_t child = leaf >> s;
                 const bool odd = child & 1;
                 const int j = odd ? lo - 1 : hi;
-                float os = sib_s[s], om = sib_m[s];
+                float os = sr.s[s], om = sr.m[s];
                 if (odd ? lo > 0 : hi < cnt) {
                     const int4 q = buf[j];
                     if ((q.w >> s) == (child ^ 1)) {            // the neighbouring run is my sibling
@@ -242,13 +264,33 @@ __device__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, fl
     }
 }
 
+// all three in one workgroup: among equal leaves the highest t wins
+__device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
+                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+    const bool active = (int)threadIdx.x < cnt;
+    const int64_t cap = rp.tree_capacity;
+    const int levels = 63 - __clzll((unsigned long long)cap);
+    const int32_t leaf = active ? (int32_t)((int64_t)my_idx | cap) : (int32_t)cap;
+    TREE_STAMP(4);
+    SibRegs sr;
+    tree_sib_prefetch(rp, leaf, active, levels, sib, sib_stride, sr);
+    TREE_STAMP(23);
+    const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, levels, lds);
+    tree_write_levels(rp, leaf, p, cnt, levels, lds, sr);
+}
+
 // whole PrioritizedSampler.update_priority for one batch, executed by ONE workgroup (any size)
 // `lds`: PER_UPDATE_LDS_BYTES of 16-byte aligned LDS supplied by the calling kernel (so that kernels
 // hosting this routine as one role among others can alias it with their own scratch).
+// `plan_out` (optional, needs n <= min(UPD_MAX, blockDim.x)): stop after the preparation and leave
+// {value, lo | hi << 16, leaf, rank} per element there; per_update_finish completes the job (in a
+// later kernel, so that the two halves hide behind different neighbours).
 constexpr int PER_UPDATE_LDS_BYTES = TREE_WRITE_LDS_BYTES + 128;
-__device__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
+template <bool PREPARE_ONLY = false>
+__device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
-                                 char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+                                 char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0,
+                                 int4 *__restrict__ plan_out = nullptr) {
     float *s_red = reinterpret_cast<float *>(lds + TREE_WRITE_LDS_BYTES);
     const int tid = threadIdx.x;
     const int pass = min(UPD_MAX, (int)blockDim.x);
@@ -285,13 +327,45 @@ __device__ void per_update_block(const prism_replay_desc &rp, const int64_t *__r
         }
         if (tid < cnt) val = pow_alpha(p0 + eps, alpha);
         TREE_STAMP(3);
-        block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride);   // a record is only
-        if (base == 0 && tid == 0) {                                                       // valid for one pass
+        if (PREPARE_ONLY) {                                     // (the caller guarantees n <= pass)
+            const int64_t cap = rp.tree_capacity;
+            const int levels = 63 - __clzll((unsigned long long)cap);
+            const int32_t leaf = tid < cnt ? (int32_t)((int64_t)me | cap) : (int32_t)cap;
+            const TreePrep p = tree_write_prepare(me, leaf, val, cnt, levels, lds);
+            if (tid < cnt) plan_out[tid] = make_int4(__float_as_int(p.val), p.lo | (p.hi << 16), leaf, p.rank);
+        } else {
+            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride);   // a record is only
+        }                                                                                      // valid for one pass
+        if (base == 0 && tid == 0) {
             float mm = old_max;                                 // (s_red was published before the first barrier)
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, s_red[w]);
             rp.per_state[0] = mm;
         }
     }
+}
+
+// second half of a prepared update: `plan` as left by per_update_block(plan_out); n <= blockDim.x.
+// `sib_state` (optional): 1 = `sib` holds the siblings of exactly these paths; consumed (reset to 0).
+__device__ __forceinline__ void per_update_finish(const prism_replay_desc &rp, const int4 *__restrict__ plan, int n, char *lds,
+                                  const float2 *__restrict__ sib, int sib_stride, unsigned int *sib_state) {
+    const int tid = threadIdx.x;
+    const bool active = tid < n;
+    const int64_t cap = rp.tree_capacity;
+    const int levels = 63 - __clzll((unsigned long long)cap);
+    // everything this block needs from global memory is requested here, in one go: the plan, the
+    // record state and (speculatively) the recorded siblings
+    const int4 pl = active ? plan[tid] : make_int4(0, 0, (int)cap, 0);
+    const unsigned int rec = sib_state ? *sib_state : 0u;
+    SibRegs sr;
+    if (sib) tree_sib_prefetch(rp, pl.z, active, levels, sib, sib_stride, sr);
+    if (!sib || rec != 1u) tree_sib_prefetch(rp, pl.z, active, levels, nullptr, 0, sr);       // uniform; rare
+    TreePrep p;
+    p.val = __int_as_float(pl.x);
+    p.lo = pl.y & 0xffff;
+    p.hi = pl.y >> 16;
+    p.rank = pl.w;
+    tree_write_levels(rp, pl.z, p, n, levels, lds, sr);
+    if (sib_state && tid == 0) *sib_state = 0u;
 }
 
 static __global__ __launch_bounds__(1024) void per_update_kernel(prism_replay_desc rp, const int64_t *__restrict__ index,

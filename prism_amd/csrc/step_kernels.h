@@ -228,11 +228,16 @@ struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as 
     prism_replay_desc rp;
     const int64_t *index;
     const float2 *sib;        // sibling record of the front kernel's descents ([level][B])
-    unsigned int *sib_state;  // 0 = none, 1 = valid for `index`, 2 = unusable (a sample was clamped); consumed here
+    unsigned int *sib_state;  // 0 = none, 1 = valid for `index`, 2 = unusable (a sample was clamped); consumed by
+                              // whoever runs the level walk
+    int4 *plan;               // non-NULL: only prepare here (ranking, winners); step_back_kernel finishes
     float alpha, eps;
     int enabled, block;
 };
 
+// WB_FULL: the writeback block runs the whole update (batches above 256); otherwise it only prepares
+// it (two instantiations: the full writer's register arrays would otherwise tax every role with spills)
+template <bool WB_FULL>
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb) {
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
     constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
@@ -242,10 +247,14 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     __shared__ float s_red[64];
     PRISM_STAMP(13);
     if (wb.enabled && (int)blockIdx.x == wb.block) {
-        const unsigned int rec = wb.sib_state ? *wb.sib_state : 0u;
-        per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, rec == 1u ? wb.sib : nullptr,
-                         a.B);
-        if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;      // (every thread read it before its first barrier)
+        if (!WB_FULL) {
+            per_update_block<true>(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, nullptr, 0, wb.plan);
+        } else {
+            const unsigned int rec = wb.sib_state ? *wb.sib_state : 0u;
+            per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, rec == 1u ? wb.sib : nullptr,
+                             a.B);
+            if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;  // (every thread read it before its first barrier)
+        }
         PRISM_STAMP(14);
         return;
     }
@@ -405,6 +414,9 @@ struct BackArgs {
     int n;
     float alpha, eps;
     int take_abs, use_per;
+    const int4 *plan;          // non-NULL: the post kernel prepared this writeback; finish it here
+    const float2 *sib;
+    unsigned int *sib_state;
     uint64_t *rng;
     uint64_t inc_per, inc_tau;
 };
