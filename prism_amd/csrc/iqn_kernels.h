@@ -158,18 +158,28 @@ __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int h, int lane) 
 // Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS
 __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
                                                 float *__restrict__ dst, int tid, int nthreads) {
-    for (int n = tid; n < E_DIM; n += nthreads) {
-        const int c = n >> 6, y = (n >> 3) & 7, x = n & 7;
-        float acc = s_b[c];
-        const float *w = s_w + c * C * 9;
-        for (int ci = 0; ci < C; ++ci)
+    // thread = output position (y, x) x a group of four output channels c0, c0 + 4, c0 + 8, c0 + 12:
+    // the 3x3 input patch of a channel is read once and feeds all four (their weight reads are
+    // wave-uniform broadcasts).  Per output the fmaf chain runs (ci, dy, dx)-major from the bias,
+    // exactly as in the one-output-at-a-time form.
+    const int c0 = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
+    float acc[4];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+    for (int k = 0; k < 4; ++k) acc[k] = s_b[c0 + 4 * k];
+    for (int ci = 0; ci < C; ++ci) {
+        float p[9];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
-                    acc = fmaf(w[ci * 9 + dy * 3 + dx], s_obs[((y + dy) * 10 + (x + dx)) * C + ci], acc);
-        dst[n] = fmaxf(acc, 0.f);
+        for (int t = 0; t < 9; ++t) p[t] = s_obs[((y + t / 3) * 10 + (x + t % 3)) * C + ci];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *w = s_w + ((c0 + 4 * k) * C + ci) * 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[k] = fmaf(w[t], p[t], acc[k]);
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[(c0 + 4 * k) * 64 + (tid & 63)] = fmaxf(acc[k], 0.f);
+    (void)nthreads;     // (256 threads: E_DIM / 4 positions-by-group)
 }
 
 __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red);

@@ -58,10 +58,52 @@ __device__ float block_tree_query(const float2 *__restrict__ v, int64_t cap, int
     __syncthreads();
     float ret = ident;
     // identity entries fold as no-ops for min; for the sum they add +0.0f which is exact
-    // (ret is never -0.0f here), so folding all 128 slots in order equals the sequential walk.
-    for (int i = 0; i < 128; ++i) ret = tree_op<MIN>(ret, scratch[i]);
+    // (ret is never -0.0f here), so folding every slot of a live level in order equals the
+    // sequential walk (levels above the root are all identity: skip them).
+    const int used = 2 * (64 - __clzll((unsigned long long)cap));
+    for (int i = 0; i < used && i < 128; ++i) ret = tree_op<MIN>(ret, scratch[i]);
     __syncthreads();
     return ret;
+}
+
+// The same query for sum and min at once, split so that the caller can put the node fetch in flight
+// together with its other loads: thread t < 128 fetches its node (identity if none), the values go
+// to scratch[t] / scratch[128 + t], and after a barrier tree_query_fold() folds them in the
+// sequential order.
+__device__ __forceinline__ float2 tree_query_fetch(const float2 *__restrict__ v, int64_t cap, int64_t tree_size,
+                                                   int64_t r_in) {
+    float2 val = make_float2(0.0f, FLT_MAX);
+    const int t = threadIdx.x;
+    if (t >= 128) return val;
+    if (r_in >= tree_size) return t == 0 ? v[1] : val;          // whole tree: 0 + root, min(FLT_MAX, root)
+    const int level = t >> 1, side = t & 1;
+    int64_t l = cap, r = r_in | cap;
+    bool live = true;
+    for (int i = 0; i < level && live; ++i) {
+        if (!(l < r)) { live = false; break; }
+        if (l & 1) ++l;
+        if (r & 1) --r;
+        l >>= 1;
+        r >>= 1;
+    }
+    if (live && l < r) {
+        if (side == 0) {
+            if (l & 1) val = v[l];
+        } else {
+            if (r & 1) val = v[r - 1];
+        }
+    }
+    return val;
+}
+__device__ __forceinline__ float2 tree_query_fold(const float *scratch, int64_t cap) {
+    const int used = 2 * (64 - __clzll((unsigned long long)cap));
+    float s = 0.0f, m = FLT_MAX;
+    for (int i = 0; i < used && i < 128; ++i) {
+        s = s + scratch[i];
+        const float c = scratch[128 + i];
+        m = m < c ? m : c;
+    }
+    return make_float2(s, m);
 }
 
 static __global__ void replay_init_kernel(prism_replay_desc rp) {
@@ -474,12 +516,9 @@ __device__ __forceinline__ int64_t tree_descend_record(const prism_replay_desc &
     int64_t node = 1;
     float v = mass;
     int s = 63 - __clzll((unsigned long long)cap);
-    while (node < cap) {
+    auto step = [&](const float4 ch) {      // ch = {left.sum, left.min, right.sum, right.min} of `node`'s children
         node <<= 1;
         --s;
-        // {left.sum, left.min, right.sum, right.min}: one aligned 16-byte load
-        const float4 ch = node < top ? *reinterpret_cast<const float4 *>(&s_top[node])
-                                     : reinterpret_cast<const float4 *>(rp.tree)[node >> 1];
         const bool right = v > ch.x;
         if (right) {
             v -= ch.x;
@@ -487,6 +526,36 @@ __device__ __forceinline__ int64_t tree_descend_record(const prism_replay_desc &
         }
         sib[(int64_t)s * stride] = right ? make_float2(ch.x, ch.y) : make_float2(ch.z, ch.w);
         *leaf_sum = right ? ch.z : ch.x;
+    };
+    while (node < cap && 2 * node < top) step(*reinterpret_cast<const float4 *>(&s_top[2 * node]));
+    // Below the LDS top every level costs a full memory round trip, so fetch three levels per trip:
+    // the 2 + 4 + 8 descendants of `node` are three contiguous, aligned runs (16 + 32 + 64 bytes,
+    // the last exactly one cache line) whose addresses are known before any of them arrives.
+    const float4 *t4 = reinterpret_cast<const float4 *>(rp.tree);
+    while (node < cap) {
+        const int64_t n = node;
+        const bool two = 2 * n < cap, three = 4 * n < cap;
+        const float4 a0 = t4[n];
+        float4 b0, b1, c0, c1, c2, c3;
+        if (two) {
+            b0 = t4[2 * n];
+            b1 = t4[2 * n + 1];
+        }
+        if (three) {
+            c0 = t4[4 * n];
+            c1 = t4[4 * n + 1];
+            c2 = t4[4 * n + 2];
+            c3 = t4[4 * n + 3];
+        }
+        // (selections spelled as two-way register selects: an indexed pick lands in scratch memory)
+        auto sel = [](bool hi, const float4 &x, const float4 &y) {
+            return make_float4(hi ? y.x : x.x, hi ? y.y : x.y, hi ? y.z : x.z, hi ? y.w : x.w);
+        };
+        step(a0);
+        const bool r1 = node & 1;
+        if (two) step(sel(r1, b0, b1));
+        const bool r2 = node & 1;
+        if (three) step(sel(r1, sel(r2, c0, c1), sel(r2, c2, c3)));
     }
     return node ^ cap;
 }

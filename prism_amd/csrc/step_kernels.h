@@ -87,7 +87,7 @@ struct FrontArgs {
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
 __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
-    __shared__ float s_scratch[128];
+    __shared__ float s_scratch[256];
     __shared__ float s_obs[2][1000];
     __shared__ float s_w[2][16 * 10 * 9];
     __shared__ float s_b[2][16];
@@ -99,28 +99,65 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         front_extra_block(a, b - B, s_scratch);
         return;
     }
-    // conv weights of both networks: independent of everything else, get them in flight first
+    PRISM_STAMP(27);
+    // Everything that does not depend on the sampled index is requested in ONE round of loads into
+    // registers (conv weights of both networks, the tree top, the nodes of the p_sum / p_min query)
+    // and only then parked in LDS: every separate wait here is a full memory round trip.
     const float *P0 = a.params, *P1 = a.has_target ? a.target_params : a.params;
     const int nw = 16 * C * 9;
-#pragma unroll 4
-    for (int i = tid; i < nw; i += 256) {
-        s_w[0][i] = P0[a.off.conv_w + i];
-        s_w[1][i] = P1[a.off.conv_w + i];
+    const int64_t cap = rp.tree_capacity;
+    const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
+    float wr[2][6], br[2] = {0.f, 0.f};
+    float2 tr[TOP_NODES / 256], qv = make_float2(0.f, FLT_MAX);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 256 * k;
+        wr[0][k] = wr[1][k] = 0.f;
+        if (i < nw) {
+            wr[0][k] = P0[a.off.conv_w + i];
+            wr[1][k] = P1[a.off.conv_w + i];
+        }
     }
     if (tid < 16) {
-        s_b[0][tid] = P0[a.off.conv_b + tid];
-        s_b[1][tid] = P1[a.off.conv_b + tid];
+        br[0] = P0[a.off.conv_b + tid];
+        br[1] = P1[a.off.conv_b + tid];
+    }
+    if (f.use_per) {
+#pragma unroll
+        for (int k = 0; k < TOP_NODES / 256; ++k) {
+            const int i = tid + 256 * k;
+            tr[k] = make_float2(0.f, 0.f);
+            if (i < top) tr[k] = tree_nodes(rp)[i];
+        }
+        qv = tree_query_fetch(tree_nodes(rp), cap, rp.capacity, f.size);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nw) {
+            s_w[0][i] = wr[0][k];
+            s_w[1][i] = wr[1][k];
+        }
+    }
+    if (tid < 16) {
+        s_b[0][tid] = br[0];
+        s_b[1][tid] = br[1];
     }
     int64_t idx;
     if (f.use_per) {
-        const int64_t cap = rp.tree_capacity;
-        const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
-#pragma unroll 8
-        for (int i = tid; i < top; i += 256) s_top[i] = tree_nodes(rp)[i];
-        const float p_sum = block_tree_query<false>(tree_nodes(rp), cap, rp.capacity, f.size, s_scratch);
-        const float p_min = block_tree_query<true>(tree_nodes(rp), cap, rp.capacity, f.size, s_scratch);
+#pragma unroll
+        for (int k = 0; k < TOP_NODES / 256; ++k) {
+            const int i = tid + 256 * k;
+            if (i < top) s_top[i] = tr[k];
+        }
+        if (tid < 128) {
+            s_scratch[tid] = qv.x;
+            s_scratch[128 + tid] = qv.y;
+        }
         __syncthreads();
         if (tid == 0) {
+            const float2 pq = tree_query_fold(s_scratch, cap);
+            const float p_sum = pq.x, p_min = pq.y;
             if (b == 0) {
                 rp.per_state[1] = p_sum;
                 rp.per_state[2] = p_min;
@@ -129,6 +166,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
                 if (!(p_min > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PMIN;
                 if (st) atomicOr(rp.status, st);
             }
+            PRISM_STAMP(28);
             float mass;
             if (f.mass) {
                 mass = f.mass[b];
@@ -161,6 +199,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         f.out_index[b] = idx;
         s_i64[0] = idx;
     }
+    PRISM_STAMP(29);
     if (tid == 0) {
         const NStepResult ns = nstep_walk(rp, idx);
         s_i64[1] = ns.last;
@@ -170,6 +209,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         f.nonterminal[b] = (ns.flags & PRISM_FLAG_DONE) ? 0 : 1;
         f.action[b] = (int64_t)rp.action[idx];
     }
+    PRISM_STAMP(30);
     __syncthreads();
     const int O = rp.obs_elems;     // == 100 * C
     const float *src_obs = rp.obs + s_i64[0] * O;
@@ -186,6 +226,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     __syncthreads();
     conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);
     conv_embed_rows(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
+    PRISM_STAMP(31);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -36,8 +36,11 @@ print(f"   total {np.median(b[:, 4] - b[:, 0]):9.0f}   start spread {b[:, 0].max
 bt = s[:nb, [12, 26]].astype(np.float64)
 if bt[:, 1].any(): print("   conv tail:", int(np.median(bt[:, 1] - bt[:, 0])))
 
-# post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
 B = cfg.batch_size
+fr = s[:B, 27:32].astype(np.float64)
+if fr[:, 0].any():
+    print("front sample blocks (top+query | descent | n-step | gather+conv): med", [int(np.median(fr[:, k + 1] - fr[:, k])) for k in range(4)], "total", int(np.median(fr[:, 4] - fr[:, 0])))
+# post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
 n_conv = 1 if (cfg.use_iqn and not cfg.use_ids and not cfg.use_dqn) else (B + 3) // 4
 pb = s[:, 13] != 0
 ps_, pe_ = s[pb, 13].astype(np.float64), s[pb, 14].astype(np.float64)
