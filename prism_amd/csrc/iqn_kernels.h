@@ -44,6 +44,7 @@ struct IqnPass {
     int save;             // current-state pass: keep what backward needs
     int stream_id;        // 0 cur, 1 next-online, 2 next-target
     int kind;             // 0: IQN quantile rows, 1: Q-head rows (w1_pk = packed W1 of all heads, head-major)
+    int loss_role;        // fused loss (IqnArgs::loss_in_fwd): 1 = publishes its quantile rows, 2 = owns the loss
 };
 
 struct IqnWs {           // workspace pointers (device)
@@ -67,6 +68,7 @@ struct IqnWs {           // workspace pointers (device)
     float *normpart;     // [NORM_SLOTS]
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
     float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
+    unsigned int *loss_flag;   // [B*T/16] publisher count per current-state tile (zero-initialised, self-resetting)
     unsigned int *ticket;   // [4] {adam, conv, -, sibling-record state}, zero-initialised by the caller, self-resetting
 };
 
@@ -81,6 +83,8 @@ struct IqnArgs {
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
     int conv_in_bwd;       // conv-backward partials are produced by the tail of iqn_bwd_kernel (bwd_conv_ok)
+    int loss_in_fwd;       // > 0: the current-state tiles of tile_fwd run the loss of their samples once this many
+                           // next-state passes have published their rows (no separate iqn_loss_kernel launch)
     int head_layers;       // 2: LN-Linear-ReLU-LN-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
@@ -374,10 +378,300 @@ __device__ __forceinline__ void tile_trunk_head(const IqnArgs &a, const TrunkPar
         for (int aa = 0; aa < 16; ++aa)
             if (aa < A) {
                 const float z = wave_sum(y0 * w2a[aa] + y1 * w2b[aa]) + b2r[aa];
-                if (lane == 0) z_out[(int64_t)m * A + aa] = z;
+                // write-through: a workgroup of this same launch may consume the row (fused loss)
+                if (lane == 0) __hip_atomic_store(&z_out[(int64_t)m * A + aa], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
     }
     PRISM_STAMP(7);
+}
+
+constexpr int LOSS_WAVES = 8;
+constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
+
+// One sample's quantile-Huber loss + head/LayerNorm(128) backward, by a 512-thread workgroup.
+// `lds`: LOSS_LDS_FLOATS floats.  `coherent_next`: the next-state quantile rows were written by other
+// workgroups of the SAME launch (fused tail of tile_fwd) -> read them with agent-scope loads.
+constexpr int LOSS_LDS_FLOATS = 3 * 64 * 16 + 4 * 64 + LOSS_WAVES * (4 * 64 + 4) + 4;
+__device__ __forceinline__ void iqn_loss_sample(const IqnArgs &a, int b, float *lds, bool coherent_next) {
+    float *s_zc = lds, *s_zo = s_zc + 64 * 16, *s_zt = s_zo + 64 * 16;
+    float *s_y = s_zt + 64 * 16, *s_q = s_y + 64, *s_tau = s_q + 64, *s_dq = s_tau + 64;
+    float(*s_acc)[4 * 64 + 4] = reinterpret_cast<float(*)[4 * 64 + 4]>(s_dq + 64);
+    int &s_astar = *reinterpret_cast<int *>(s_dq + 64 + LOSS_WAVES * (4 * 64 + 4));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
+    const float kap = a.huber_k;
+
+    // rows of this wave: t = w, w + 8, ...; start their loads now, they do not depend on the loss
+    float xa[LOSS_RPW], xb[LOSS_RPW], pa[LOSS_RPW], pb[LOSS_RPW], rs[LOSS_RPW];
+#pragma unroll
+    for (int i = 0; i < LOSS_RPW; ++i) {
+        const int t = w + LOSS_WAVES * i;
+        if (t < T) {
+            const int64_t r = (int64_t)b * T + t;
+            xa[i] = a.ws.xhat2[r * H_DIM + lane];
+            xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
+            pa[i] = a.ws.pre1[r * H_DIM + lane];
+            pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
+            rs[i] = a.ws.rstd2[r];
+        }
+    }
+    const int act = (int)a.action[b];
+    const float *P = a.params;
+    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
+    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
+    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
+    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
+    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
+
+    for (int i = tid; i < T * A; i += 64 * LOSS_WAVES) s_zc[i] = a.ws.zcur[(int64_t)b * T * A + i];
+    for (int i = tid; i < Tn * A; i += 64 * LOSS_WAVES) {
+        const float *po = a.ws.zon + (int64_t)b * Tn * A + i, *pt = a.ws.ztg + (int64_t)b * Tn * A + i;
+        s_zo[i] = coherent_next ? __hip_atomic_load(po, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *po;
+        s_zt[i] = coherent_next ? __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *pt;
+    }
+    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
+    if (tid < T) s_tau[tid] = a.tau_out[(int64_t)tid * B + b];
+    __syncthreads();
+    PRISM_STAMP(20);
+    if (tid == 0) {
+        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133)
+        int best = 0;
+        float bestv = 0.f;
+        for (int aa = 0; aa < A; ++aa) {
+            float s = 0.f;
+            for (int j = 0; j < Tn; ++j) s += s_zo[j * A + aa];
+            s = s / (float)Tn;
+            if (aa == 0 || s > bestv) {
+                bestv = s;
+                best = aa;
+            }
+        }
+        s_astar = best;
+    }
+    __syncthreads();
+    PRISM_STAMP(21);
+    if (w == 0) {
+        const float R = a.reward[b];
+        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + s_astar] * dg;   // separate mul and add (iqn_model.py:145)
+        if (lane < T) s_q[lane] = s_zc[lane * A + act];
+        __builtin_amdgcn_wave_barrier();
+        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
+        float lsum = 0.f, gq = 0.f;
+        const int t_l = lane % T;
+        const float q_l = s_q[t_l], tau_l = s_tau[t_l];
+        for (int p = lane; p < T * Tn; p += 64) {
+            const int j = p / T;
+            const float d = s_y[j] - q_l;
+            const float ad = fabsf(d);
+            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
+            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
+            lsum += (wgt * hub) / kap;
+            const float cl = fminf(fmaxf(d, -kap), kap);
+            gq += (wgt * cl) / kap;
+        }
+        lsum = wave_sum(lsum);
+        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
+        const float dl = (lsum / (float)Tn) * a.dist_w;
+        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+        const float scale = -(wb / (float)B) * a.dist_w / (float)Tn;
+        if (lane < T) s_dq[lane] = gq * scale;
+        if (lane == 0) {
+            a.out_dl[b] = dl;
+            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
+            a.ws.lossw[b] = dl * wb;
+        }
+    }
+    __syncthreads();
+    PRISM_STAMP(22);
+
+    // head + LayerNorm(128) backward for this wave's rows
+    float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LOSS_RPW; ++i) {
+        const int t = w + LOSS_WAVES * i;
+        if (t < T) {
+            const int64_t r = (int64_t)b * T + t;
+            const float dq = s_dq[t];
+            const float da = dq * w2a, db = dq * w2b;
+            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
+            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
+            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
+            ga = pa[i] > 0.f ? ga : 0.f;
+            gb = pb[i] > 0.f ? gb : 0.f;
+            a.ws.dpre1[r * H_DIM + lane] = ga;
+            a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
+            const float c1 = wave_sum(ga * ua + gb * ub);
+            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+            if (lane == 0) {
+                a.ws.c1[r] = c1;
+                a.ws.c2[r] = c2;
+                a.ws.dq[r] = dq;
+            }
+            Sa += dq * xa[i];
+            Sbb += dq * xb[i];
+            Pa += ga;
+            Pbb += gb;
+            Dsum += dq;
+        }
+    }
+    s_acc[w][lane] = Sa;
+    s_acc[w][64 + lane] = Sbb;
+    s_acc[w][128 + lane] = Pa;
+    s_acc[w][192 + lane] = Pbb;
+    if (lane == 0) s_acc[w][256] = Dsum;
+    __syncthreads();
+    PRISM_STAMP(23);
+    if (tid < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][tid];
+        if (tid < 128) a.ws.Sb[(int64_t)b * H_DIM + tid] = t;
+        else a.ws.Pb[(int64_t)b * H_DIM + (tid - 128)] = t;
+    } else if (tid == 256) {
+        float t = 0.f;
+        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][256];
+        a.ws.Db[b] = t;
+    }
+}
+
+// The same computation for ALL samples of one 16-row current-state tile at once (fused tail of
+// tile_fwd; needs 16 % T == 0 and Tn == T, so the tile's samples own next-state rows r0..r0+15 too).
+// Wave w owns tile rows 2w and 2w+1; the first wave of a sample's group computes its argmax and
+// quantile-Huber block.  The next-state rows come from other workgroups of this launch: agent-scope loads.
+constexpr int LOSS_TILE_LDS_FLOATS = 3 * 256 + 4 * 16 + LOSS_WAVES * (4 * 64 + 4);
+__device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *lds) {
+    float *s_zc = lds, *s_zo = s_zc + 256, *s_zt = s_zo + 256;          // [16 rows][A <= 16]
+    float *s_y = s_zt + 256, *s_q = s_y + 16, *s_tau = s_q + 16, *s_dq = s_tau + 16;
+    float(*s_acc)[4 * 64 + 4] = reinterpret_cast<float(*)[4 * 64 + 4]>(s_dq + 16);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int B = a.B, A = a.A, T = a.T;
+    const float kap = a.huber_k;
+    const int wps = T / 2;                       // waves per sample (8 waves x 2 rows = 16 rows)
+    const int smp = (2 * w) / T;                 // local sample of this wave
+    const int b = r0 / T + smp;
+    const int t0 = 2 * w - smp * T;              // this wave's rows are quantiles t0, t0 + 1 of sample b
+    float xa[2], xb[2], pa[2], pb[2], rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = (int64_t)r0 + 2 * w + i;
+        xa[i] = a.ws.xhat2[r * H_DIM + lane];
+        xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
+        pa[i] = a.ws.pre1[r * H_DIM + lane];
+        pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
+        rs[i] = a.ws.rstd2[r];
+    }
+    const int act = (int)a.action[b];
+    const float *P = a.params;
+    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
+    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
+    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
+    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
+    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
+    const float R = a.reward[b];
+    const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+    const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+    if (tid < 16 * A) {
+        s_zc[tid] = a.ws.zcur[(int64_t)r0 * A + tid];
+        s_zo[tid] = __hip_atomic_load(a.ws.zon + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_zt[tid] = __hip_atomic_load(a.ws.ztg + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
+    if (tid < 16) s_tau[tid] = a.tau_out[(int64_t)(tid % T) * B + (r0 / T + tid / T)];
+    __syncthreads();
+    if (w % wps == 0) {
+        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133): lane = action
+        float mean = 0.f;
+        if (lane < A) {
+            float sacc = 0.f;
+            for (int j = 0; j < T; ++j) sacc += s_zo[(smp * T + j) * A + lane];
+            mean = sacc / (float)T;
+        }
+        int astar = 0;
+        float bestv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), 0));
+#pragma unroll
+        for (int aa = 1; aa < 16; ++aa) {
+            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), aa));
+            if (aa < A && m > bestv) {
+                bestv = m;
+                astar = aa;
+            }
+        }
+        float *y = s_y + smp * T, *q = s_q + smp * T;
+        if (lane < T) y[lane] = R + s_zt[(smp * T + lane) * A + astar] * dg;   // separate mul and add (iqn_model.py:145)
+        if (lane < T) q[lane] = s_zc[(smp * T + lane) * A + act];
+        __builtin_amdgcn_wave_barrier();
+        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
+        float lsum = 0.f, gq = 0.f;
+        const int t_l = lane % T;
+        const float q_l = q[t_l], tau_l = s_tau[smp * T + t_l];
+        for (int p = lane; p < T * T; p += 64) {
+            const int j = p / T;
+            const float d = y[j] - q_l;
+            const float ad = fabsf(d);
+            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
+            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
+            lsum += (wgt * hub) / kap;
+            const float cl = fminf(fmaxf(d, -kap), kap);
+            gq += (wgt * cl) / kap;
+        }
+        lsum = wave_sum(lsum);
+        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
+        const float dl = (lsum / (float)T) * a.dist_w;
+        const float scale = -(wb / (float)B) * a.dist_w / (float)T;
+        if (lane < T) s_dq[smp * T + lane] = gq * scale;
+        if (lane == 0) {
+            a.out_dl[b] = dl;
+            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
+            a.ws.lossw[b] = dl * wb;
+        }
+    }
+    __syncthreads();
+    // head + LayerNorm(128) backward for this wave's two rows
+    float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = (int64_t)r0 + 2 * w + i;
+        const float dq = s_dq[2 * w + i];
+        const float da = dq * w2a, db = dq * w2b;
+        const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
+        const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
+        float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
+        ga = pa[i] > 0.f ? ga : 0.f;
+        gb = pb[i] > 0.f ? gb : 0.f;
+        a.ws.dpre1[r * H_DIM + lane] = ga;
+        a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
+        const float c1 = wave_sum(ga * ua + gb * ub);
+        const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+        if (lane == 0) {
+            a.ws.c1[r] = c1;
+            a.ws.c2[r] = c2;
+            a.ws.dq[r] = dq;
+        }
+        Sa += dq * xa[i];
+        Sbb += dq * xb[i];
+        Pa += ga;
+        Pbb += gb;
+        Dsum += dq;
+    }
+    (void)t0;
+    s_acc[w][lane] = Sa;
+    s_acc[w][64 + lane] = Sbb;
+    s_acc[w][128 + lane] = Pa;
+    s_acc[w][192 + lane] = Pbb;
+    if (lane == 0) s_acc[w][256] = Dsum;
+    __syncthreads();
+    // per sample: fold its group of waves in order
+    const int ns = 16 / T;
+    for (int o = tid; o < ns * 257; o += 64 * LOSS_WAVES) {
+        const int sm = o / 257, k = o - sm * 257;
+        float t = 0.f;
+        for (int ww = 0; ww < wps; ++ww) t += s_acc[sm * wps + ww][k];
+        const int bb = r0 / T + sm;
+        if (k < 128) a.ws.Sb[(int64_t)bb * H_DIM + k] = t;
+        else if (k < 256) a.ws.Pb[(int64_t)bb * H_DIM + (k - 128)] = t;
+        else a.ws.Db[bb] = t;
+    }
 }
 
 __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
@@ -521,6 +815,25 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     TileSave sv{ps.save ? a.ws.mu1 : nullptr, a.ws.rstd1, ps.save ? a.ws.pre1 : nullptr, ps.save ? a.ws.xhat2 : nullptr,
                 a.ws.rstd2, (int64_t)r0};
     tile_trunk_head(a, tp, sv, ytile, h1, part, bt, ps.z_out + (int64_t)r0 * A, A);
+    if (!a.loss_in_fwd) return;
+    // ---- fused loss: the next-state tile(s) of these samples publish, the current-state tile consumes.
+    // Launch order puts every publisher at a lower workgroup index than its consumer, so a waiting
+    // consumer never holds a CU that its publisher still needs.
+    __syncthreads();                     // all rows of this tile are out (the barrier waits for vmcnt(0))
+    PRISM_STAMP(16);
+    if (ps.loss_role == 1) {
+        if (tid == 0) __hip_atomic_fetch_add(&a.ws.loss_flag[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (ps.loss_role == 2) {
+        if (tid == 0) {
+            while (__hip_atomic_load(&a.ws.loss_flag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.loss_in_fwd)
+                __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_store(&a.ws.loss_flag[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        PRISM_STAMP(17);
+        iqn_loss_tile(a, r0, smem);
+        PRISM_STAMP(18);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -529,145 +842,9 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
 // current-state rows are back-propagated through head + LayerNorm(128), rows strided over waves.
 // T, T' must divide 64.
 // ------------------------------------------------------------------------------------------
-constexpr int LOSS_WAVES = 8;
-constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
-
 __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
-    __shared__ float s_zc[64 * 16], s_zo[64 * 16], s_zt[64 * 16];
-    __shared__ float s_y[64], s_q[64], s_tau[64], s_dq[64];
-    __shared__ float s_acc[LOSS_WAVES][4 * 64 + 4];
-    __shared__ int s_astar;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
-    const float kap = a.huber_k;
-
-    // rows of this wave: t = w, w + 8, ...; start their loads now, they do not depend on the loss
-    float xa[LOSS_RPW], xb[LOSS_RPW], pa[LOSS_RPW], pb[LOSS_RPW], rs[LOSS_RPW];
-#pragma unroll
-    for (int i = 0; i < LOSS_RPW; ++i) {
-        const int t = w + LOSS_WAVES * i;
-        if (t < T) {
-            const int64_t r = (int64_t)b * T + t;
-            xa[i] = a.ws.xhat2[r * H_DIM + lane];
-            xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
-            pa[i] = a.ws.pre1[r * H_DIM + lane];
-            pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
-            rs[i] = a.ws.rstd2[r];
-        }
-    }
-    const int act = (int)a.action[b];
-    const float *P = a.params;
-    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
-    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
-    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
-    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
-    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
-
-    for (int i = tid; i < T * A; i += 64 * LOSS_WAVES) s_zc[i] = a.ws.zcur[(int64_t)b * T * A + i];
-    for (int i = tid; i < Tn * A; i += 64 * LOSS_WAVES) {
-        s_zo[i] = a.ws.zon[(int64_t)b * Tn * A + i];
-        s_zt[i] = a.ws.ztg[(int64_t)b * Tn * A + i];
-    }
-    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
-    if (tid < T) s_tau[tid] = a.tau_out[(int64_t)tid * B + b];
-    __syncthreads();
-    if (tid == 0) {
-        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133)
-        int best = 0;
-        float bestv = 0.f;
-        for (int aa = 0; aa < A; ++aa) {
-            float s = 0.f;
-            for (int j = 0; j < Tn; ++j) s += s_zo[j * A + aa];
-            s = s / (float)Tn;
-            if (aa == 0 || s > bestv) {
-                bestv = s;
-                best = aa;
-            }
-        }
-        s_astar = best;
-    }
-    __syncthreads();
-    if (w == 0) {
-        const float R = a.reward[b];
-        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + s_astar] * dg;   // separate mul and add (iqn_model.py:145)
-        if (lane < T) s_q[lane] = s_zc[lane * A + act];
-        __builtin_amdgcn_wave_barrier();
-        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
-        float lsum = 0.f, gq = 0.f;
-        const int t_l = lane % T;
-        const float q_l = s_q[t_l], tau_l = s_tau[t_l];
-        for (int p = lane; p < T * Tn; p += 64) {
-            const int j = p / T;
-            const float d = s_y[j] - q_l;
-            const float ad = fabsf(d);
-            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
-            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
-            lsum += (wgt * hub) / kap;
-            const float cl = fminf(fmaxf(d, -kap), kap);
-            gq += (wgt * cl) / kap;
-        }
-        lsum = wave_sum(lsum);
-        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
-        const float dl = (lsum / (float)Tn) * a.dist_w;
-        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
-        const float scale = -(wb / (float)B) * a.dist_w / (float)Tn;
-        if (lane < T) s_dq[lane] = gq * scale;
-        if (lane == 0) {
-            a.out_dl[b] = dl;
-            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
-            a.ws.lossw[b] = dl * wb;
-        }
-    }
-    __syncthreads();
-
-    // head + LayerNorm(128) backward for this wave's rows
-    float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < LOSS_RPW; ++i) {
-        const int t = w + LOSS_WAVES * i;
-        if (t < T) {
-            const int64_t r = (int64_t)b * T + t;
-            const float dq = s_dq[t];
-            const float da = dq * w2a, db = dq * w2b;
-            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
-            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
-            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
-            ga = pa[i] > 0.f ? ga : 0.f;
-            gb = pb[i] > 0.f ? gb : 0.f;
-            a.ws.dpre1[r * H_DIM + lane] = ga;
-            a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
-            const float c1 = wave_sum(ga * ua + gb * ub);
-            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
-            if (lane == 0) {
-                a.ws.c1[r] = c1;
-                a.ws.c2[r] = c2;
-                a.ws.dq[r] = dq;
-            }
-            Sa += dq * xa[i];
-            Sbb += dq * xb[i];
-            Pa += ga;
-            Pbb += gb;
-            Dsum += dq;
-        }
-    }
-    s_acc[w][lane] = Sa;
-    s_acc[w][64 + lane] = Sbb;
-    s_acc[w][128 + lane] = Pa;
-    s_acc[w][192 + lane] = Pbb;
-    if (lane == 0) s_acc[w][256] = Dsum;
-    __syncthreads();
-    if (tid < 256) {
-        float t = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][tid];
-        if (tid < 128) a.ws.Sb[(int64_t)b * H_DIM + tid] = t;
-        else a.ws.Pb[(int64_t)b * H_DIM + (tid - 128)] = t;
-    } else if (tid == 256) {
-        float t = 0.f;
-        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][256];
-        a.ws.Db[b] = t;
-    }
+    __shared__ __attribute__((aligned(16))) float s_loss[LOSS_LDS_FLOATS];
+    iqn_loss_sample(a, blockIdx.x, s_loss, false);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -215,6 +215,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.normpart = c.f(NORM_SLOTS);
     w.sib = c.f((size_t)TREE_MAX_LEVELS * B * 2);
     w.wb_plan = c.f((size_t)B * 4);
+    w.loss_flag = (unsigned int *)c.f(R / 16 + 4);
     {
         const size_t Hd = d->n_heads, RQ = Hd * (size_t)B;
         w.q_mu1 = c.f(RQ);
@@ -293,6 +294,12 @@ static int check_learner(const prism_learner_desc *ld) {
 // beside clip + Adam (back launch, 256-thread workgroups: one leaf per thread)
 static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 256; }
 
+// the IQN loss runs in the tail of the current-state tiles of tile_fwd when a 16-row tile holds whole
+// samples and the next-state rows of those samples form the tile of the same index
+static int loss_in_fwd(const prism_model_dims &d) {
+    return d.use_iqn && d.n_tau <= 16 && 16 % d.n_tau == 0 && d.n_tau_next == d.n_tau ? 1 : 0;
+}
+
 static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(ld->batch);
@@ -350,28 +357,34 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     int np = 0;
     const float *pk0 = a.ws.wpk[0], *pk1 = a.ws.wpk[1];
     if (d.use_iqn) {
-        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
-                               B * d.n_tau / 16, 1, 0, 0};
+        // launch order: next-state passes first, the current-state pass last (fused loss, see tile_fwd);
+        // the tau draws are tied to stream_id, not to this order
+        const int fuse = loss_in_fwd(d);
+        a.loss_in_fwd = 0;
         if (!d.has_target || d.double_q) {
             a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_online, a.ws.zon,
-                                   d.n_tau_next, B * d.n_tau_next / 16, 0, 1, 0};
+                                   d.n_tau_next, B * d.n_tau_next / 16, 0, 1, 0, fuse ? 1 : 0};
+            a.loss_in_fwd += fuse;
         }
         if (d.has_target) {
             a.pass[np++] = IqnPass{ld->target_params, pk1, pk1 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_target,
-                                   a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2, 0};
+                                   a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2, 0, fuse ? 1 : 0};
+            a.loss_in_fwd += fuse;
         }
+        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
+                               B * d.n_tau / 16, 1, 0, 0, fuse ? 2 : 0};
         if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
         else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
     }
     if (d.n_heads > 0 && d.head_layers == 2) {
         // Q-head tiles: (B/16) x heads per pass; same online/target selection (q_ensemble.py:62-68)
         const int nt = (B / 16) * d.n_heads;
-        a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_cur, nullptr, a.ws.zq_cur, 1, nt, 1, 0, 1};
+        a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_cur, nullptr, a.ws.zq_cur, 1, nt, 1, 0, 1, 0};
         if (!d.has_target || d.double_q)
-            a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_next, nullptr, a.ws.zq_on, 1, nt, 0, 1, 1};
+            a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_next, nullptr, a.ws.zq_on, 1, nt, 0, 1, 1, 0};
         if (d.has_target)
             a.pass[np++] = IqnPass{ld->target_params, nullptr, a.ws.q_wpk[1], a.ws.e_next, nullptr, a.ws.zq_tg, 1, nt, 0, 2,
-                                   1};
+                                   1, 0};
         if (!d.has_target) a.ws.zq_tg = a.ws.zq_on;
         else if (!d.double_q) a.ws.zq_on = a.ws.zq_tg;
     }
@@ -443,8 +456,8 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
         PRISM_CHECK_LAUNCH();
     }
-    // losses first (TD errors final), then fork the priority writeback, then the backward kernels
-    if (ld->dims.use_iqn) {
+    // losses first (TD errors final), then the backward kernels
+    if (ld->dims.use_iqn && !a.loss_in_fwd) {
         ProfileScope ps_(K_LOSS, stream);
         hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
         PRISM_CHECK_LAUNCH();

@@ -27,6 +27,10 @@ print("tile_fwd (median over 256 workgroups, shader-clock ticks):")
 for k in range(7):
     print(f"   {names[k]:24s} {np.median(f[:, k + 1] - f[:, k]):9.0f}")
 print(f"   total {np.median(f[:, 7] - f[:, 0]):9.0f}   start spread {f[:, 0].max() - f[:, 0].min():9.0f}   end spread {f[:, 7].max() - f[:, 7].min():9.0f}")
+ow = s[128:256, [7, 16, 17, 18, 19]].astype(np.float64)
+if ow[:, 2].any(): print("   fused loss tail of the current-state tiles (barrier | wait | sample 0 | sample 1):", [int(np.median(ow[:, k + 1] - ow[:, k])) for k in range(4)])
+lw = s[128:256, [18, 20, 21, 22, 23, 19]].astype(np.float64)
+if lw[:, 1].any(): print("   loss of sample 1 (loads+stage | argmax | huber | LN backward | reduce+store):", [int(np.median(lw[:, k + 1] - lw[:, k])) for k in range(5)])
 nb = int((s[:, 8] != 0).sum())
 b = s[:nb, 8:13].astype(np.float64)
 print(f"bwd ({nb} workgroups):")
