@@ -1197,12 +1197,17 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         const int s = i / (100 * C), o = i - s * 100 * C;
         s_obs[s * 1000 + o] = a.obs[(int64_t)(b0 + s) * 100 * C + o];
     }
-#pragma unroll 4
+#pragma unroll 2
     for (int i = tid; i < ns * E_DIM; i += 1024) {
         const int s = i >> 10, n = i & 1023;
         const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
         float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
-        for (int hd = 0; hd < a.n_heads; ++hd) d += a.ws.de_q[(size_t)hd * B * E_DIM + o];   // heads in fixed order
+        float dh[16];                                    // every head's value requested before the first add
+#pragma unroll
+        for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.n_heads ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
+#pragma unroll
+        for (int hd = 0; hd < 16; ++hd)
+            if (hd < a.n_heads) d += dh[hd];             // heads in fixed order
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
@@ -1248,53 +1253,66 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
     }
 }
 
-// b1, LN2 affine, W2, b2 gradients for the 16 hidden units [slice*16, slice*16+16).
-//   S[a][h] = sum_{b: act=a} Sb[b][h];  D[a] = sum_{b: act=a} Db[b];  db1[h] = sum_b Pb[b][h]
+// b1, LN2 affine, W2, b2 gradients of one [LN -> Linear(H -> A)] head for the 16 hidden units
+// [slice*16, slice*16+16), shared by the IQN head and the Q-ensemble heads:
+//   S[a][h] = sum_{b: act=a} v(b,h);  D[a] = sum_{b: act=a} d(b);  db1[h] = sum_b p(b,h)
 //   dW2[a][h] = g2[h] S[a][h] + beta2[h] D[a];  dg2[h] = sum_a W2[a][h] S[a][h];  dbeta2[h] = sum_a W2[a][h] D[a]
-// 1024 threads = 16 units x 64 batch parts.  Slice 0 also writes db2 and the IQN part of the total loss.
-// Latency-shaped: every global operand is requested up front, the 64 batch parts of all A+1
-// per-unit sums are folded in ONE LDS pass (16 reads + a quad reduction per thread), and the tail
-// runs as (action, unit) threads.  `pool`: SMALL_POOL_FLOATS floats of LDS.
+// (+ kappa * theta on every tensor when the Theil regulariser is on).
+// 1024 threads = 16 units x 64 batch parts.  Latency-shaped: every global operand is requested up
+// front, the 64 batch parts of all A+1 per-unit sums (and of D, riding in a 17th column) are folded
+// in ONE LDS pass (16 reads + a quad reduction per thread), and the tail runs as (action, unit)
+// threads.  `pool`: SMALL_POOL_FLOATS floats of LDS.
 constexpr int SMALL_W = 16;
 constexpr int SMALL_GROUP = 8;                                   // per-unit sums folded per LDS pass
 constexpr int SMALL_POOL_FLOATS = SMALL_GROUP * 64 * 17;
-__device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq, float *pool) {
+struct SmallIo {
+    const float *w2, *g2, *be2, *b1, *b2;   // parameters of the head (b1, b2 only read with kappa)
+    float *gw2, *gg2, *gbe2, *gb1, *gb2;    // their gradients
+    float kappa;
+    bool use_kappa;
+    const float *extra;                     // optional [B]: slice 0 leaves sum_b extra[b] in *extra_sum (thread 0)
+};
+// load(b, h, want_d) -> {v, p, d}
+template <typename Load>
+__device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, float &sq, float *pool, const SmallIo &io,
+                                                 Load load, float *extra_sum) {
     __shared__ float s_S[17][SMALL_W];      // [A] = b1 row
     __shared__ float s_D[16];
     __shared__ float s_lw[16];
     __shared__ float s_dgb[2][16][SMALL_W];
     const int tid = threadIdx.x, B = a.B, A = a.A;
     const int hl = tid & (SMALL_W - 1), part = tid >> 4, h = slice * SMALL_W + hl;
-    float *gr = a.grads;
-    const float *P = a.params;
     // tail operands of thread (action ta, unit hl): requested now, used last
     const int ta = tid >> 4;
-    float w2 = 0.f, g2 = 0.f, be2 = 0.f;
+    float w2 = 0.f, g2 = 0.f, be2 = 0.f, b1v = 0.f, b2v = 0.f;
     if (ta < A) {
-        w2 = P[a.off.iqn_w2 + ta * H_DIM + h];
-        g2 = P[a.off.iqn_ln2_g + h];
-        be2 = P[a.off.iqn_ln2_b + h];
+        w2 = io.w2[ta * H_DIM + h];
+        g2 = io.g2[h];
+        be2 = io.be2[h];
+    }
+    if (io.use_kappa) {
+        if (tid >= 2 * SMALL_W && tid < 3 * SMALL_W) b1v = io.b1[h];
+        if (slice == 0 && tid < A) b2v = io.b2[tid];
     }
     float sA[16], dA[16];
 #pragma unroll
     for (int aa = 0; aa < 16; ++aa) sA[aa] = dA[aa] = 0.f;
     float pb = 0.f;
-    float lw = (slice == 0 && tid < B) ? a.ws.lossw[tid] : 0.f;
-#pragma unroll 4
+    float lw = (io.extra && slice == 0 && tid < B) ? io.extra[tid] : 0.f;
+#pragma unroll 8
     for (int b = part; b < B; b += 64) {
-        const float v = a.ws.Sb[(int64_t)b * H_DIM + h];
-        pb += a.ws.Pb[(int64_t)b * H_DIM + h];
-        const float dv = hl == 0 ? a.ws.Db[b] : 0.f;            // column 16 of the fold: D[a] partials
+        const float3 x = load(b, h, hl == 0);                   // d rides in column 16 of the fold
+        pb += x.y;
         const int ab = (int)a.action[b];
 #pragma unroll
         for (int aa = 0; aa < 16; ++aa) {
-            sA[aa] += (ab == aa) ? v : 0.f;
-            dA[aa] += (ab == aa) ? dv : 0.f;
+            sA[aa] += (ab == aa) ? x.x : 0.f;
+            dA[aa] += (ab == aa) ? x.z : 0.f;
         }
     }
     PRISM_STAMP(16);
-    if (slice == 0) {
-        for (int b = 1024 + tid; b < B; b += 1024) lw += a.ws.lossw[b];
+    if (io.extra && slice == 0) {
+        for (int b = 1024 + tid; b < B; b += 1024) lw += io.extra[b];
         lw = wave_sum(lw);
         if ((tid & 63) == 0) s_lw[tid >> 6] = lw;
     }
@@ -1332,11 +1350,13 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
     }
     __syncthreads();
     PRISM_STAMP(18);
+    const float k = io.kappa;
     float dg = 0.f, db = 0.f;
     if (ta < A) {
         const float S = s_S[ta][hl], D = s_D[ta];
-        const float dw = g2 * S + be2 * D;
-        gr[a.off.iqn_w2 + ta * H_DIM + h] = dw;
+        float dw = g2 * S + be2 * D;
+        if (io.use_kappa) dw += k * w2;
+        io.gw2[ta * H_DIM + h] = dw;
         sq += dw * dw;
         dg = w2 * S;
         db = w2 * D;
@@ -1350,24 +1370,46 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
         const int which = tid >> 4;
         float t = 0.f;
         for (int aa = 0; aa < A; ++aa) t += s_dgb[which][aa][hl];
-        gr[(which ? a.off.iqn_ln2_b : a.off.iqn_ln2_g) + h] = t;
+        if (io.use_kappa) t += k * (which ? io.be2[h] : io.g2[h]);
+        (which ? io.gbe2 : io.gg2)[h] = t;
         sq += t * t;
     } else if (tid < 3 * SMALL_W) {
-        const float t = s_S[A][hl];
-        gr[a.off.iqn_b1 + h] = t;
+        float t = s_S[A][hl];
+        if (io.use_kappa) t += k * b1v;
+        io.gb1[h] = t;
         sq += t * t;
     }
     PRISM_STAMP(19);
     if (slice == 0 && tid < A) {
-        const float D = s_D[tid];
-        gr[a.off.iqn_b2 + tid] = D;
+        float D = s_D[tid];
+        if (io.use_kappa) D += k * b2v;
+        io.gb2[tid] = D;
         sq += D * D;
     }
-    if (slice == 0 && tid == 0) {
+    if (io.extra && slice == 0 && tid == 0) {
         float l = 0.f;
 #pragma unroll
         for (int p = 0; p < 16; ++p) l += s_lw[p];
-        l = l / (float)B;       // mean_b(dl_b * w_b)  (agent.py:58-64)
+        *extra_sum = l;
+    }
+}
+
+// IQN head: Sb / Pb / Db were left per sample by the loss; slice 0 also writes the IQN part of the total loss
+__device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq, float *pool) {
+    const float *P = a.params;
+    float *gr = a.grads;
+    SmallIo io{P + a.off.iqn_w2, P + a.off.iqn_ln2_g, P + a.off.iqn_ln2_b, P + a.off.iqn_b1, P + a.off.iqn_b2,
+               gr + a.off.iqn_w2, gr + a.off.iqn_ln2_g, gr + a.off.iqn_ln2_b, gr + a.off.iqn_b1, gr + a.off.iqn_b2,
+               0.f, false, a.ws.lossw};
+    float lsum = 0.f;
+    small_fold_block(a, slice, sq, pool, io,
+                     [&](int b, int h, bool want_d) {
+                         return make_float3(a.ws.Sb[(int64_t)b * H_DIM + h], a.ws.Pb[(int64_t)b * H_DIM + h],
+                                            want_d ? a.ws.Db[b] : 0.f);
+                     },
+                     &lsum);
+    if (slice == 0 && threadIdx.x == 0) {
+        const float l = lsum / (float)a.B;       // mean_b(dl_b * w_b)  (agent.py:58-64)
         a.out_scalars[1] = l;
         if (a.n_heads == 0) {
             a.out_scalars[0] = l;

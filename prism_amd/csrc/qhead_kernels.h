@@ -343,81 +343,20 @@ __device__ __forceinline__ void q_slab_sum(const IqnArgs &a, int64_t i, const fl
 }
 
 // b1, LN2 affine, W2, b2 gradients of head `hd` for the 64 hidden units [slice*64, +64).  1024 threads.
-__device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, int slice, const float *kappa, float &sq) {
-    __shared__ float s_part[16][64];
-    __shared__ float s_S[16][64];
-    __shared__ float s_D[16];
-    const int tid = threadIdx.x, B = a.B, A = a.A;
-    const int hl = tid & 63, part = tid >> 6, h = slice * 64 + hl;
+__device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, int slice, const float *kappa, float &sq,
+                                                     float *pool) {
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
     float *Gh = a.grads + a.off.head_base + (int64_t)hd * a.off.head_stride;
-    float sA[16];
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
-    float pb = 0.f;
-#pragma unroll 4
-    for (int b = part; b < B; b += 16) {
-        const int64_t r = (int64_t)hd * B + b;
-        const float v = a.ws.q_dq[r] * a.ws.q_xhat2[r * H_DIM + h];
-        pb += a.ws.q_dpre1[r * H_DIM + h];
-        const int ab = (int)a.action[b];
-#pragma unroll
-        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
-    }
-    {
-        float s = 0.f;
-        if (part < A)
-            for (int b = hl; b < B; b += 64) s += ((int)a.action[b] == part) ? a.ws.q_dq[(int64_t)hd * B + b] : 0.f;
-        s = wave_sum(s);
-        if (hl == 0) s_D[part] = s;
-    }
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa) {
-        if (aa < A) {
-            __syncthreads();
-            s_part[part][hl] = sA[aa];
-            __syncthreads();
-            if (part == 0) {
-                float t = 0.f;
-#pragma unroll
-                for (int p = 0; p < 16; ++p) t += s_part[p][hl];
-                s_S[aa][hl] = t;
-            }
-        }
-    }
-    __syncthreads();
-    s_part[part][hl] = pb;
-    __syncthreads();
-    const float k = kappa ? kappa[hd] : 0.f;
-    if (part == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) t += s_part[p][hl];
-        t += k * Ph[a.off.h_b1 + h];
-        Gh[a.off.h_b1 + h] = t;
-        sq += t * t;
-        const float g2 = Ph[a.off.h_ln2_g + h], be2 = Ph[a.off.h_ln2_b + h];
-        float dg = 0.f, db = 0.f;
-        for (int aa = 0; aa < A; ++aa) {
-            const float w2 = Ph[a.off.h_w2 + aa * H_DIM + h];
-            const float S = s_S[aa][hl], D = s_D[aa];
-            const float dw = g2 * S + be2 * D + k * w2;
-            Gh[a.off.h_w2 + aa * H_DIM + h] = dw;
-            sq += dw * dw;
-            dg += w2 * S;
-            db += w2 * D;
-        }
-        dg += k * g2;
-        db += k * be2;
-        Gh[a.off.h_ln2_g + h] = dg;
-        Gh[a.off.h_ln2_b + h] = db;
-        sq += dg * dg + db * db;
-    }
-    if (slice == 0 && tid < A) {
-        const float D = s_D[tid] + k * Ph[a.off.h_b2 + tid];
-        Gh[a.off.h_b2 + tid] = D;
-        sq += D * D;
-    }
+    SmallIo io{Ph + a.off.h_w2, Ph + a.off.h_ln2_g, Ph + a.off.h_ln2_b, Ph + a.off.h_b1, Ph + a.off.h_b2,
+               Gh + a.off.h_w2, Gh + a.off.h_ln2_g, Gh + a.off.h_ln2_b, Gh + a.off.h_b1, Gh + a.off.h_b2,
+               kappa ? kappa[hd] : 0.f, kappa != nullptr, nullptr};
+    const int64_t r0 = (int64_t)hd * a.B;
+    small_fold_block(a, slice, sq, pool, io,
+                     [&](int b, int h, bool) {
+                         const float dq = a.ws.q_dq[r0 + b];
+                         return make_float3(dq * a.ws.q_xhat2[(r0 + b) * H_DIM + h], a.ws.q_dpre1[(r0 + b) * H_DIM + h], dq);
+                     },
+                     nullptr);
 }
 
 }  // namespace prism

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
 // ------------------------------------------------------------------------------------------
 constexpr int POST_SLAB_BLOCKS = (SLAB / 4 + 1023) / 1024;   // 49
 constexpr int POST_SMALL_BLOCKS = H_DIM / SMALL_W;           // 8 (IQN small tensors, 16 hidden units per block)
-constexpr int POST_QSMALL_BLOCKS = H_DIM / 64;               // 2 per head
+constexpr int POST_QSMALL_BLOCKS = H_DIM / SMALL_W;          // 8 per head (16 hidden units per block)
 
 __host__ __device__ inline int post_q_slab_blocks(int n_heads) { return (n_heads * (Q_SLAB / 4) + 1023) / 1024; }
 __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd) {
@@ -423,19 +423,22 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 if (i < (int64_t)a.n_heads * (Q_SLAB / 4)) q_slab_sum(a, i, kappa, sq);
             } else {
                 const int x = blk - nqs;
-                q_small_tensor_block(a, x / POST_QSMALL_BLOCKS, x % POST_QSMALL_BLOCKS, kappa, sq);
+                // total loss (agent.py:58-64): mean(dl*w) + mean(ql*w); operands requested before the fold
+                float lw = 0.f, li = 0.f;
                 if (x == 0) {
-                    // total loss (agent.py:58-64): mean(dl*w) [already in out_scalars[1]] + mean(ql*w)
-                    float lw = 0.f;
-                    for (int b = tid; b < B; b += 1024) lw += a.ws.q_lossw[b];
+                    for (int b = tid; b < B; b += 1024) {
+                        lw += a.ws.q_lossw[b];
+                        if (a.use_iqn) li += a.ws.lossw[b];
+                    }
+                }
+                q_small_tensor_block(a, x / POST_QSMALL_BLOCKS, x % POST_QSMALL_BLOCKS, kappa, sq,
+                                     reinterpret_cast<float *>(s_pool));
+                if (x == 0) {
                     const float tq = block_sum_1024(lw, s_red);
+                    const float ti = block_sum_1024(li, s_red);
                     if (tid == 0) {
-                        float ld = 0.f;
-                        if (a.use_iqn)
-                            for (int b = 0; b < B; ++b) ld += a.ws.lossw[b];
-                        ld /= (float)B;
                         a.out_scalars[2] = tq / (float)B;
-                        a.out_scalars[0] = ld + tq / (float)B;
+                        a.out_scalars[0] = ti / (float)B + tq / (float)B;
                     }
                 }
             }

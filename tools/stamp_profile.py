@@ -64,3 +64,9 @@ if n_conv > 1: print("   conv phases (partials | publish+ticket | rest): med", [
 if n_conv > 1: print("   conv partials (stage | mac | reduce): med", [int(np.median(x)) for x in (cv[:, 22] - cv[:, 13], cv[:, 23] - cv[:, 22], cv[:, 20] - cv[:, 23])])
 print("   small phases (load | D | action rounds | b1+W2 tail | end):", [int(np.median(sm[:, 16 + k] - (sm[:, 13] if k == 0 else sm[:, 15 + k]))) for k in range(4)], int(np.median(sm[:, 14] - sm[:, 19])))
 rep("writeback", idx == idx.max())
+# generic view: the ten longest post blocks (index, duration) -- for configurations with Q-head roles
+d_ = pe_ - ps_
+order = np.argsort(-d_)[:10]
+print("   longest post blocks (index: ticks):", ", ".join(f"{int(idx[i])}: {int(d_[i])}" for i in order))
+print("   post block duration by index decile:", [int(np.median(d_[(idx >= lo_) & (idx < hi_)])) if ((idx >= lo_) & (idx < hi_)).any() else 0
+      for lo_, hi_ in zip(np.linspace(0, idx.max() + 1, 11)[:-1], np.linspace(0, idx.max() + 1, 11)[1:])])
