@@ -31,11 +31,17 @@ with open(os.path.join(dst, f"{tag}_{cfg}_kernel_stats.csv"), "w") as f:
     f.write(f'"(all non-prism kernels: torch fills/copies during setup)",,{other:.0f},,,,,\n')
 
 
+def kname(full):
+    """'void prism::iqn_post_kernel<false>(prism::IqnArgs, ...)' -> 'iqn_post_kernel'"""
+    n = full.split("(")[0].replace("prism::", "").replace("void ", "").strip()
+    return n.split("<")[0]
+
+
 def counter(pat):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(one(pat))):
         if "prism::" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("prism::", "")].append(float(r["Counter_Value"]))
+            agg[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 3:]) / len(v[len(v) // 3:]) for k, v in agg.items()}
 
 
