@@ -19,6 +19,25 @@ __global__ __launch_bounds__(64 * WAVES) void stream_kernel(const float *__restr
             float4 v = *reinterpret_cast<const float4 *>(w + i);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    } else if (MODE == 3) {
+        // coalesced, but every workgroup of an XCD starts at a different offset (no lockstep on identical lines)
+        const int chunks = n_floats / (WAVES * 64 * 4);
+        const int rot = (int)((blockIdx.x / 8) * 7919u % chunks);
+        for (int c = 0; c < chunks; ++c) {
+            int cc = c + rot;
+            if (cc >= chunks) cc -= chunks;
+            float4 v = *reinterpret_cast<const float4 *>(w + (size_t)cc * WAVES * 64 * 4 + (wv * 64 + lane) * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    } else if (MODE == 4) {
+        // coalesced, unrolled x32: as many loads in flight per wave as the tile kernels keep
+        for (int i = (wv * 64 + lane) * 4; i < n_floats; i += WAVES * 64 * 4 * 32) {
+            float4 v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = (i + u * WAVES * 64 * 4 < n_floats) ? *reinterpret_cast<const float4 *>(w + i + u * WAVES * 64 * 4) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
     } else if (MODE == 1) {
         // wave wv owns row tiles wv, wv+WAVES, ...; per tile 16 rows; per q a 64-B piece per row
         for (int rt = wv; rt < rows / 16; rt += WAVES) {
@@ -77,6 +96,8 @@ int main() {
     hipMalloc(&cyc, 4096 * 8);
     hipMemset(w, 0, n * 4);
     run<0, 8>("coalesced 1 KB/instr", w, out, n, cyc, 256);
+    run<3, 8>("coalesced, rotated start per workgroup", w, out, n, cyc, 256);
+    run<4, 8>("coalesced, 32 loads in flight per lane", w, out, n, cyc, 256);
     run<1, 8>("fragment 16 rows x 64 B", w, out, n, cyc, 256);
     run<2, 8>("fragment 8 rows x 128 B", w, out, n, cyc, 256);
     run<0, 4>("coalesced 1 KB/instr", w, out, n, cyc, 256);
