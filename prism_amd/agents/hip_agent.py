@@ -245,8 +245,11 @@ class HipAgent:
         act = batch["action"]
         if act.dim() == 2 and act.shape[-1] != 1:
             act = act.argmax(dim=-1)
+        nt = batch["nonterminal"]
+        if nt.dtype not in (torch.bool, torch.uint8):      # the kernels read one byte per sample
+            nt = nt != 0
         keep = [obs.float().contiguous(), nobs.float().contiguous(), rew.float().contiguous(),
-                batch["nonterminal"].contiguous(), batch["gamma"].float().contiguous(),
+                nt.contiguous(), batch["gamma"].float().contiguous(),
                 act.long().contiguous()]
         d.obs, d.next_obs, d.reward, d.nonterminal, d.gamma, d.action = [t.data_ptr() for t in keep]
         if torch.is_tensor(per_weights):
