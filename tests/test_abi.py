@@ -82,3 +82,32 @@ def test_product_never_imports_oracle_and_has_no_cpu_path():
             "except NativeLibraryError as e:\n    print('LOUD', e)\n" % H.ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert "LOUD" in out.stdout, out.stdout + out.stderr
+
+
+def test_kernels_use_no_scratch_memory(tmp_path):
+    """A register array that lands in scratch (private segment) costs a kernel several microseconds per
+    launch on this path (it happened three times during development: indexed selects, conditionally
+    initialised arrays, kernel-argument structs passed by reference).  Compile the device code to
+    assembly and require a zero private segment for every kernel."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    ROOT = H.ROOT
+    csrc = os.path.join(ROOT, "prism_amd", "csrc")
+    bad = []
+    for src in ("learner.hip", "replay.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-S", "--cuda-device-only",
+                        "-o", str(out), os.path.join(csrc, src)], check=True, timeout=600,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        text = out.read_text()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
+            seg = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+            uses = re.search(r"scratch_(load|store)", text[text.find(m.group(1) + ":"):text.find(".amdhsa_kernel " + m.group(1))])
+            if seg and int(seg.group(1)) > 0 and uses:
+                bad.append((m.group(1), int(seg.group(1))))
+    assert not bad, f"kernels with scratch traffic: {bad}"
