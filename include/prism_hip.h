@@ -208,10 +208,13 @@ typedef struct prism_learner_desc {
     uint64_t *rng_counters;   /* optional device [2] {PER draws, tau draws} added to the immediate offsets
                                  and advanced by prism_step_back (lets a captured hipGraph draw fresh
                                  numbers on every replay); NULL = immediate offsets only              */
-    /* Optional: when fused_replay is set, prism_learner_fwd_bwd also performs
-     * prism_per_update(fused_index, |out_td|) as one more workgroup of its last launch (the TD errors
-     * are final by then, and the writeback hides behind the gradient reduction), and prism_step_back
-     * skips its own writeback.  Results are identical. */
+    /* Optional: when fused_replay is set, prism_per_update(fused_index, |out_td|) rides along in the
+     * learner's launches instead of being a workgroup of its own in prism_step_back: one more workgroup
+     * of prism_learner_fwd_bwd's last launch prepares it (|TD|^alpha, ranking, duplicate resolution --
+     * the TD errors are final by then) and, for batches up to 256, prism_step_back walks the tree levels
+     * using the sibling values prism_step_front recorded (larger batches: all of it in fwd_bwd).
+     * With fused_replay set, prism_learner_fwd_bwd MUST be followed by prism_step_back on the same
+     * stream before the tree is read again.  Results are identical to the stand-alone update. */
     const struct prism_replay_desc *fused_replay;   /* host pointer or NULL */
     const int64_t *fused_index;                     /* [B] sampled slots */
     float fused_alpha, fused_eps;
@@ -221,7 +224,7 @@ typedef struct prism_learner_desc {
     float *out_td;            /* [B]          (td_errors, composite_model.py:135-142)         */
     float *out_scalars;       /* [8] {total loss, mean dl*w, mean ql*w, grad norm, theil, clip coef, -, -} */
     float *dbg_z;             /* optional [ (T+T')*B*A ] quantile estimates (tests) or NULL    */
-    void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][16] uint64 shader-clock stamps, else NULL */
+    void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][32] uint64 shader-clock stamps, else NULL */
     void *workspace;          /* >= prism_learner_workspace_bytes()                           */
     size_t workspace_bytes;
     prism_adam_hyper hyper;
