@@ -446,25 +446,72 @@ static __global__ void replay_store_rows_kernel(prism_replay_desc rp, int n, con
     }
 }
 
-// links (sequential, as the collector would have produced them) + default priority
+// links + default priority.  The reference applies the rows one after the other; for a batch of
+// consecutive ring slots (what a writer cursor produces) whose predecessors are not overwritten later
+// in the same batch, three parallel phases give the same final state:
+//   A  detach the old neighbours of every overwritten slot (reads the state before the batch),
+//   B  reset the slots' own link/back,   C  attach each row to its predecessor.
+// Anything else (arbitrary slot lists, a batch that wraps over its own predecessors) takes the
+// sequential path.
 static __global__ __launch_bounds__(1024) void replay_link_kernel(prism_replay_desc rp, int n,
                                                           const int32_t *__restrict__ slots,
                                                           const int32_t *__restrict__ prev_slot, float alpha,
                                                           float eps) {
     __shared__ __attribute__((aligned(16))) char s_pool[TREE_WRITE_LDS_BYTES];
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < n; ++i) {
-            const int32_t s = slots[i];
-            const int32_t b = rp.back[s];
-            if (b >= 0 && rp.link[b] == s) rp.link[b] = -1;   // predecessor of the overwritten row
-            const int32_t q = rp.link[s];
-            if (q >= 0 && rp.back[q] == s) rp.back[q] = -1;   // successor of the overwritten row
-            rp.link[s] = -1;
-            rp.back[s] = -1;
+    __shared__ int s_serial;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    if (tid == 0) s_serial = 0;
+    __syncthreads();
+    {
+        const int64_t first = slots[0], cap = rp.capacity;
+        bool bad = false;
+        for (int i = tid; i < n; i += bd) {
+            if (slots[i] != (int32_t)((first + i) % cap)) bad = true;
             const int32_t p = prev_slot[i];
             if (p >= 0) {
-                rp.link[p] = s;
-                rp.back[s] = p;
+                const int64_t pos = ((int64_t)p - first + cap) % cap;
+                if (pos < n && pos >= i) bad = true;        // predecessor overwritten at or after this row
+            }
+        }
+        if (bad) s_serial = 1;
+    }
+    __syncthreads();
+    if (s_serial) {
+        if (tid == 0) {
+            for (int i = 0; i < n; ++i) {
+                const int32_t s = slots[i];
+                const int32_t b = rp.back[s];
+                if (b >= 0 && rp.link[b] == s) rp.link[b] = -1;   // predecessor of the overwritten row
+                const int32_t q = rp.link[s];
+                if (q >= 0 && rp.back[q] == s) rp.back[q] = -1;   // successor of the overwritten row
+                rp.link[s] = -1;
+                rp.back[s] = -1;
+                const int32_t p = prev_slot[i];
+                if (p >= 0) {
+                    rp.link[p] = s;
+                    rp.back[s] = p;
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += bd) {                      // A
+            const int32_t s = slots[i];
+            const int32_t b = rp.back[s], q = rp.link[s];
+            if (b >= 0 && rp.link[b] == s) rp.link[b] = -1;
+            if (q >= 0 && rp.back[q] == s) rp.back[q] = -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += bd) {                      // B
+            const int32_t s = slots[i];
+            rp.link[s] = -1;
+            rp.back[s] = -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += bd) {                      // C
+            const int32_t p = prev_slot[i];
+            if (p >= 0) {
+                rp.link[p] = slots[i];
+                rp.back[slots[i]] = p;
             }
         }
     }

@@ -128,12 +128,19 @@ class HipReplayBuffer:
         # staging (pinned host -> device) for extend()
         S = self.STAGE_ROWS
         pin = dict(pin_memory=True)
-        self._h = dict(slots=torch.empty(S, dtype=torch.int32, **pin), obs=torch.empty(S, O, **pin),
-                       succ=torch.zeros(S, O, **pin), reward=torch.empty(S, **pin),
-                       action=torch.empty(S, dtype=torch.int32, **pin),
-                       flags=torch.empty(S, dtype=torch.uint8, **pin),
-                       prev=torch.empty(S, dtype=torch.int32, **pin))
-        self._d = {k: torch.empty_like(v, device=dev) for k, v in self._h.items()}
+        # two staging sets: extend() fills one while the H2D copies + insert kernels of the other are in
+        # flight; a set is only waited for (its event) when it comes round again
+        def _stage():
+            return dict(slots=torch.empty(S, dtype=torch.int32, **pin), obs=torch.empty(S, O, **pin),
+                        succ=torch.zeros(S, O, **pin), reward=torch.empty(S, **pin),
+                        action=torch.empty(S, dtype=torch.int32, **pin),
+                        flags=torch.empty(S, dtype=torch.uint8, **pin),
+                        prev=torch.empty(S, dtype=torch.int32, **pin))
+        self._stages = [_stage(), _stage()]
+        self._stage_dev = [{k: torch.empty_like(v, device=dev) for k, v in st.items()} for st in self._stages]
+        self._stage_ev = [None, None]
+        self._cur_stage = 0
+        self._h, self._d = self._stages[0], self._stage_dev[0]
         self._alloc_batch(self.buffer._batch_size)
 
     def _alloc_batch(self, B):
@@ -208,8 +215,15 @@ class HipReplayBuffer:
                 ctypes.byref(self._desc), n, N.ptr(d["slots"]), N.ptr(d["obs"]), N.ptr(d["succ"]),
                 N.ptr(d["reward"]), N.ptr(d["action"]), N.ptr(d["flags"]), N.ptr(d["prev"]),
                 smp._alpha, smp._eps, N.current_stream_handle()), "prism_replay_insert")
-            # the pinned staging rows are reused by the next extend(): wait for the H2D copies
-            torch.cuda.current_stream().synchronize()
+            ev = torch.cuda.Event()
+            ev.record()
+        # the other staging set takes the next rows; it was submitted a whole batch ago
+        self._stage_ev[self._cur_stage] = ev
+        self._cur_stage ^= 1
+        self._h, self._d = self._stages[self._cur_stage], self._stage_dev[self._cur_stage]
+        if self._stage_ev[self._cur_stage] is not None:
+            self._stage_ev[self._cur_stage].synchronize()
+            self._stage_ev[self._cur_stage] = None
         self._n_staged = 0
 
     @torch.no_grad()

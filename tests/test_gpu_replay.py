@@ -245,3 +245,43 @@ def test_uniform_replay_and_empty_errors(dev):
                      torch.zeros(60))
     with pytest.raises(RuntimeError):
         pbuf.sample()
+
+
+@pytest.mark.parametrize("cap,n_env,total,seed", [(257, 4, 1500, 0), (64, 3, 700, 1), (1000, 8, 2500, 2)])
+def test_interleaved_env_chains_wrap_the_ring(dev, cap, n_env, total, seed):
+    """Several collectors' episodes interleaved round-robin, flushed in random batch sizes, wrapping a
+    small ring many times: link/back/flags and the priority tree must equal the oracle's one-row-at-a-time
+    insert (the device links a whole batch in three parallel phases, or row by row when a batch wraps
+    over its own predecessors)."""
+    from oracle import per_ref
+    from prism_amd.experience import Timestep
+    buf = _mk_buffer(dev, cap, 16, n_step=3, gamma=0.99, use_per=True)
+    orc = per_ref.ReplayOracle(cap, 400, 3, 0.99)
+    rng = np.random.default_rng(seed)
+    new_obs = lambda: torch.from_numpy((rng.random((10, 10, 4)) < 0.1).astype(np.float32))
+    ids = iter(range(10 ** 9))
+    cur = [Timestep(id=next(ids), obs=new_obs()) for _ in range(n_env)]
+    prev_slot = [-1] * n_env
+    next_flush = int(rng.integers(1, min(cap, 200)))
+    for i in range(total):
+        e = i % n_env
+        t = cur[e]
+        nxt = Timestep(id=next(ids), obs=new_obs())
+        t.reward, t.action = float(np.float32(rng.standard_normal())), int(rng.integers(0, 6))
+        t.done, t.truncated = bool(rng.random() < 0.07), False
+        if not t.done:
+            t.next = weakref.ref(nxt)
+        s = buf.extend(t)
+        so = orc.insert(t.obs.numpy(), nxt.obs.numpy() if not t.done else None, t.reward, t.action, t.done, False,
+                        not t.done, prev_slot[e])
+        assert s == so
+        prev_slot[e] = -1 if t.done else s
+        cur[e] = nxt
+        if buf._n_staged >= next_flush:
+            buf.flush()
+            next_flush = int(rng.integers(1, min(cap, 200)))
+    buf.flush()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(buf.link.cpu().numpy(), orc.link)
+    np.testing.assert_array_equal(buf.flags.cpu().numpy(), orc.flags)
+    np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), orc.sampler.sum_tree.values())
