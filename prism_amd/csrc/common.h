@@ -63,27 +63,6 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
-// Full-line weight fetch for the MFMA B operand.  A 16x(K) weight tile is fetched as two loads per
-// 32-wide K chunk: load L1 covers rows 0-7 and load L2 rows 8-15 of the tile, each lane taking 16 B at
-// k = 32c + 16*(li>>3) + 4g, so one wave instruction reads 8 rows x 128 contiguous bytes (whole
-// cache lines) instead of 16 rows x 64 B.  Lane li then owns one half of its row and its partner
-// li^8 the other; two DPP row_ror:8 moves with bank masks put them right:
-//   kA (k = 32c + 4g + jj)      = li < 8 ? L1 : partner's L2
-//   kB (k = 32c + 16 + 4g + jj) = li < 8 ? partner's L1 : L2
-template <int BANK_MASK>
-__device__ __forceinline__ float dpp_ror8_into(float keep, float from_partner) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(from_partner), 0x128, 0xF,
-                                                      BANK_MASK, false));
-}
-__device__ __forceinline__ float4 frag_kA(const float4 &L1, const float4 &L2) {
-    return float4{dpp_ror8_into<0xC>(L1.x, L2.x), dpp_ror8_into<0xC>(L1.y, L2.y), dpp_ror8_into<0xC>(L1.z, L2.z),
-                  dpp_ror8_into<0xC>(L1.w, L2.w)};
-}
-__device__ __forceinline__ float4 frag_kB(const float4 &L1, const float4 &L2) {
-    return float4{dpp_ror8_into<0x3>(L2.x, L1.x), dpp_ror8_into<0x3>(L2.y, L1.y), dpp_ror8_into<0x3>(L2.z, L1.z),
-                  dpp_ror8_into<0x3>(L2.w, L1.w)};
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_move<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
     v += dpp_move<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
