@@ -272,6 +272,16 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
         s_rec[rank] = make_int4(__float_as_int(cs), __float_as_int(cm), lo | (hi << 16), leaf);
         tree_nodes(rp)[leaf] = make_float2(cs, cm);
     }
+    // Every prefetched sibling value lands HERE, once, and is then laundered through an empty asm: the
+    // compiler otherwise keeps "a load may still be pending" alive through the level bodies and puts an
+    // s_waitcnt vmcnt(0) into each of them -- which also waits for that level's fire-and-forget store.
+    float ss[TREE_MAX_LEVELS], sm[TREE_MAX_LEVELS];
+#pragma unroll
+    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+        ss[s] = sr.s[s];
+        sm[s] = sr.m[s];
+        asm volatile("" : "+v"(ss[s]), "+v"(sm[s]));
+    }
     lds_only_barrier();
     TREE_STAMP(5);
 #pragma unroll
@@ -282,17 +292,13 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
             if (active) {
                 const int32_t child = leaf >> s;
                 const bool odd = child & 1;
-                const int j = odd ? lo - 1 : hi;
-                float os = sr.s[s], om = sr.m[s];
-                if (odd ? lo > 0 : hi < cnt) {
-                    const int4 q = buf[j];
-                    if ((q.w >> s) == (child ^ 1)) {            // the neighbouring run is my sibling
-                        os = __int_as_float(q.x);
-                        om = __int_as_float(q.y);
-                        lo = min(lo, q.z & 0xffff);
-                        hi = max(hi, q.z >> 16);
-                    }
-                }
+                // branch-free: ONE 16-byte read of the neighbouring record (my own when there is none)
+                const bool has = odd ? lo > 0 : hi < cnt;
+                const int4 q = buf[has ? (odd ? lo - 1 : hi) : rank];
+                const bool meet = has && (q.w >> s) == (child ^ 1);      // the neighbouring run is my sibling
+                const float os = meet ? __int_as_float(q.x) : ss[s], om = meet ? __int_as_float(q.y) : sm[s];
+                lo = meet ? min(lo, q.z & 0xffff) : lo;
+                hi = meet ? max(hi, q.z >> 16) : hi;
                 const float ls = odd ? os : cs, rs = odd ? cs : os;
                 const float lm = odd ? om : cm, rm = odd ? cm : om;
                 cs = ls + rs;
