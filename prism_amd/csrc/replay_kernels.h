@@ -561,7 +561,9 @@ __device__ __forceinline__ int64_t tree_descend(const prism_replay_desc &rp, con
 }
 
 // The same descent over the interleaved tree with a float2 LDS top, which also records for every
-// level s (0 = leaf level) {sum, min} of the sibling of the node it steps into: sib[s * stride].
+// level s (0 = leaf level) {sum, min} of the sibling of the node it steps into: sib[s * stride]
+// (give it LDS: a global store issued between the loads of the lower levels makes every later load
+// wait for the store's acknowledgement as well -- loads and stores share one in-order counter).
 __device__ __forceinline__ int64_t tree_descend_record(const prism_replay_desc &rp, const float2 *s_top, int64_t top,
                                                        float mass, float2 *sib, int stride, float *leaf_sum) {
     const int64_t cap = rp.tree_capacity;

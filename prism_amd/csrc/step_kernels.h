@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     __shared__ float s_w[2][16 * 10 * 9];
     __shared__ float s_b[2][16];
     __shared__ int64_t s_i64[2];
+    __shared__ float2 s_sibrec[TREE_MAX_LEVELS];
+    __shared__ float s_out_w;
+    __shared__ unsigned int s_rec_state;
     __shared__ uint32_t s_flags;
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -179,16 +182,15 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
             // the descent reads both children of every path node; the one it does not step into is
             // exactly what the priority writeback needs later -> record it, level-major
             float leaf_sum = 0.f;
-            idx = tree_descend_record(rp, s_top, top, mass, reinterpret_cast<float2 *>(a.ws.sib) + b, B, &leaf_sum);
+            idx = tree_descend_record(rp, s_top, top, mass, s_sibrec, 1, &leaf_sum);
             unsigned int rec = 1u;                                  // 1 = record valid, 2 = not usable
             if (idx > f.size - 1) {
                 idx = f.size - 1;
                 leaf_sum = tree_nodes(rp)[idx | cap].x;
                 rec = 2u;
             }
-            if (b == 0 || rec == 2u) atomicMax(a.ws.ticket + 3, rec);
-            f.out_index[b] = idx;
-            f.out_weight[b] = pow_neg_beta(leaf_sum / p_min, f.beta);
+            s_out_w = pow_neg_beta(leaf_sum / p_min, f.beta);       // stored after the n-step walk's loads
+            s_rec_state = rec;
             s_i64[0] = idx;
         }
     } else if (tid == 0) {
@@ -196,7 +198,6 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         Philox ph(f.seed);
         ph(f.offset + (f.rng ? f.rng[0] : 0ull) + (uint64_t)b, 0x554e4946ull, r);
         idx = (int64_t)__umul64hi(((uint64_t)r[0] << 32) | r[1], (uint64_t)f.size);
-        f.out_index[b] = idx;
         s_i64[0] = idx;
     }
     PRISM_STAMP(29);
@@ -208,9 +209,17 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         f.gamma[b] = (float)ns.gamma;
         f.nonterminal[b] = (ns.flags & PRISM_FLAG_DONE) ? 0 : 1;
         f.action[b] = (int64_t)rp.action[idx];
+        f.out_index[b] = idx;
+        if (f.use_per) {
+            f.out_weight[b] = s_out_w;
+            if (b == 0 || s_rec_state == 2u) atomicMax(a.ws.ticket + 3, s_rec_state);
+        }
     }
     PRISM_STAMP(30);
     __syncthreads();
+    // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
+    if (f.use_per && tid >= 64 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity))
+        reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
     const int O = rp.obs_elems;     // == 100 * C
     const float *src_obs = rp.obs + s_i64[0] * O;
     const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
