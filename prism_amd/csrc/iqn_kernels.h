@@ -1045,14 +1045,28 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         // dWphi[n-slice][64] += dphi^T (16 cols x 16 rows) . cos (16 rows x 64)   (A = dpp: D layout == A^T layout)
         // dW1[128][n-slice]  += dpre1^T (128 x 16 rows) . X (16 rows x 16 cols)    (B = xv)
         // k-step outer, accumulator inner: consecutive MFMAs never touch the same accumulator
+        // The 12 LDS operands of a k-step are read as ONE batch, one k-step ahead of the MFMAs that
+        // use them (left to itself the compiler reads two values, waits, issues two MFMAs, ...: the
+        // matrix pipe then idles for an LDS round trip every other instruction).
+        float cv[2][4], dv[2][8];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) cv[0][kt] = cosl[(4 * g) * CS + 16 * kt + j];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) dv[0][mt] = dpl[(4 * g) * HS + 16 * mt + j];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (r < 3) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-                accWphi[kt] = mfma16(dpp[r], cosl[(4 * g + r) * CS + 16 * kt + j], accWphi[kt]);
+                for (int kt = 0; kt < 4; ++kt) cv[(r + 1) & 1][kt] = cosl[(4 * g + r + 1) * CS + 16 * kt + j];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-                accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
+                for (int mt = 0; mt < 8; ++mt) dv[(r + 1) & 1][mt] = dpl[(4 * g + r + 1) * HS + 16 * mt + j];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the read batch ahead of this k-step's MFMAs
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) accWphi[kt] = mfma16(dpp[r], cv[r & 1][kt], accWphi[kt]);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) accW1[mt] = mfma16(dv[r & 1][mt], xv[r], accW1[mt]);
         }
         // conv taps of (sample bsm, channel cs>>2, output position (y0 + (j>>3), j&7)); LDS reads of
         // this wave's own earlier writes need no barrier
