@@ -540,7 +540,9 @@ __device__ __forceinline__ void iqn_loss_sample(const IqnArgs &a, int b, float *
 // Wave w owns tile rows 2w and 2w+1; the first wave of a sample's group computes its argmax and
 // quantile-Huber block.  The next-state rows come from other workgroups of this launch: agent-scope loads.
 constexpr int LOSS_TILE_LDS_FLOATS = 3 * 256 + 4 * 16 + LOSS_WAVES * (4 * 64 + 4);
-__device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *lds) {
+// `flag` / `need`: the publisher count of this tile; waited for only after every operand that does not
+// depend on the publishers has been requested.
+__device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *lds, unsigned int *flag, unsigned int need) {
     float *s_zc = lds, *s_zo = s_zc + 256, *s_zt = s_zo + 256;          // [16 rows][A <= 16]
     float *s_y = s_zt + 256, *s_q = s_y + 16, *s_tau = s_q + 16, *s_dq = s_tau + 16;
     float(*s_acc)[4 * 64 + 4] = reinterpret_cast<float(*)[4 * 64 + 4]>(s_dq + 16);
@@ -571,13 +573,19 @@ __device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *l
     const float R = a.reward[b];
     const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
     const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+    if (tid < 16 * A) s_zc[tid] = a.ws.zcur[(int64_t)r0 * A + tid];
+    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
+    if (tid < 16) s_tau[tid] = a.tau_out[(int64_t)(tid % T) * B + (r0 / T + tid / T)];
+    // everything above is this workgroup's own data; now the publishers' rows
+    if (tid == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
+        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     if (tid < 16 * A) {
-        s_zc[tid] = a.ws.zcur[(int64_t)r0 * A + tid];
         s_zo[tid] = __hip_atomic_load(a.ws.zon + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_zt[tid] = __hip_atomic_load(a.ws.ztg + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
-    if (tid < 16) s_tau[tid] = a.tau_out[(int64_t)(tid % T) * B + (r0 / T + tid / T)];
     __syncthreads();
     if (w % wps == 0) {
         // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133): lane = action
@@ -824,14 +832,8 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     if (ps.loss_role == 1) {
         if (tid == 0) __hip_atomic_fetch_add(&a.ws.loss_flag[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (ps.loss_role == 2) {
-        if (tid == 0) {
-            while (__hip_atomic_load(&a.ws.loss_flag[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.loss_in_fwd)
-                __builtin_amdgcn_s_sleep(2);
-            __hip_atomic_store(&a.ws.loss_flag[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
         PRISM_STAMP(17);
-        iqn_loss_tile(a, r0, smem);
+        iqn_loss_tile(a, r0, smem, &a.ws.loss_flag[tile], (unsigned)a.loss_in_fwd);
         PRISM_STAMP(18);
     }
 }
