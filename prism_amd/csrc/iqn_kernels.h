@@ -1143,25 +1143,36 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
     }
     __syncthreads();
     float *slab = a.ws.slabs + (int64_t)rc * SLAB;
-    for (int idx = tid; idx < BWD_ACC * 64; idx += 256) {
-        const int slot = idx >> 6, l = idx & 63;
-        const float v = ((red[(0 * BWD_ACC + slot) * 64 + l] + red[(1 * BWD_ACC + slot) * 64 + l]) +
-                         red[(2 * BWD_ACC + slot) * 64 + l]) + red[(3 * BWD_ACC + slot) * 64 + l];
-        const int lj = l & 15, lg = l >> 4;
-        if (slot < 16) {
-            // accWphi[kt][r]: row (n index) = 4*lg + r, col (basis) = 16*kt + lj
-            const int kt = slot >> 2, r = slot & 3;
-            slab[(int64_t)(cs * 16 + 4 * lg + r) * K_BASIS + 16 * kt + lj] = v;
-        } else if (slot < 48) {
-            // accW1[mt][r]: row h = 16*mt + 4*lg + r, col n = cs*16 + lj
-            const int mt = (slot - 16) >> 2, r = (slot - 16) & 3;
-            slab[(int64_t)(E_DIM * K_BASIS + 3 * E_DIM) + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
-        } else if (lg == 0) {
-            const int nn = cs * 16 + lj;
-            if (slot == 48) slab[E_DIM * K_BASIS + E_DIM + nn] = v;           // d ln1_g
-            else if (slot == 49) slab[E_DIM * K_BASIS + 2 * E_DIM + nn] = v;  // d ln1_b
-            else slab[E_DIM * K_BASIS + nn] = v;                              // d phi_b
-        }
+    // slot = w + 4 i for this thread (256 threads = 4 slots of 64 lanes per sweep): the slot's register
+    // index r is the wave number, its tile index the sweep number -- affine addresses, no div/mod
+    auto fold4 = [&](int slot) {
+        return ((red[(0 * BWD_ACC + slot) * 64 + lane] + red[(1 * BWD_ACC + slot) * 64 + lane]) +
+                red[(2 * BWD_ACC + slot) * 64 + lane]) + red[(3 * BWD_ACC + slot) * 64 + lane];
+    };
+    {
+        // accWphi[kt][r = w]: row (n index) = 4*g + r, col (basis) = 16*kt + j
+        float *dst = slab + (int64_t)(cs * 16 + 4 * g + w) * K_BASIS + j;
+        float v[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) v[kt] = fold4(w + 4 * kt);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) dst[16 * kt] = v[kt];
+    }
+    {
+        // accW1[mt][r = w]: row h = 16*mt + 4*g + r, col n = cs*16 + j
+        float *dst = slab + (int64_t)(E_DIM * K_BASIS + 3 * E_DIM) + (int64_t)(4 * g + w) * E_DIM + cs * 16 + j;
+        float v[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) v[mt] = fold4(16 + w + 4 * mt);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) dst[(int64_t)16 * mt * E_DIM] = v[mt];
+    }
+    if (w < 3 && g == 0) {
+        const float v = fold4(48 + w);
+        const int nn = cs * 16 + j;
+        if (w == 0) slab[E_DIM * K_BASIS + E_DIM + nn] = v;           // d ln1_g
+        else if (w == 1) slab[E_DIM * K_BASIS + 2 * E_DIM + nn] = v;  // d ln1_b
+        else slab[E_DIM * K_BASIS + nn] = v;                          // d phi_b
     }
     PRISM_STAMP(12);
     if (!n_mine) return;
