@@ -159,7 +159,11 @@ __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int h, int lane) 
     }
 }
 
-// Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS
+// Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS.
+// `s_w`: the 3x3 taps of every (out channel, in channel) pair padded to CONV_W_PAD floats, 16-byte aligned
+// (conv_w_slot maps a flat weight index to its LDS slot): three 16-byte reads per pair instead of nine.
+constexpr int CONV_W_PAD = 12;
+__device__ __forceinline__ int conv_w_slot(int i) { return (i / 9) * CONV_W_PAD + i % 9; }
 __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
                                                 float *__restrict__ dst, int tid, int nthreads) {
     // thread = output position (y, x) x a group of four output channels c0, c0 + 4, c0 + 8, c0 + 12:
@@ -176,7 +180,9 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
         for (int t = 0; t < 9; ++t) p[t] = s_obs[((y + t / 3) * 10 + (x + t % 3)) * C + ci];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float *w = s_w + ((c0 + 4 * k) * C + ci) * 9;
+            const float4 *w4 = reinterpret_cast<const float4 *>(s_w + ((c0 + 4 * k) * C + ci) * CONV_W_PAD);
+            const float4 wa = w4[0], wb = w4[1], wc = w4[2];
+            const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[k] = fmaf(w[t], p[t], acc[k]);
         }
@@ -190,7 +196,7 @@ __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red);
 
 __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
     __shared__ float s_obs[1024];
-    __shared__ float s_w[16 * 10 * 9];
+    __shared__ __attribute__((aligned(16))) float s_w[16 * 10 * CONV_W_PAD];
     __shared__ float s_b[16];
     const int B = a.B, C = a.C;
     const int blk = blockIdx.x, tid = threadIdx.x;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
 #pragma unroll 4
     for (int i = tid; i < 100 * C; i += 256) s_obs[i] = src[i];
 #pragma unroll 4
-    for (int i = tid; i < 16 * C * 9; i += 256) s_w[i] = P[a.off.conv_w + i];
+    for (int i = tid; i < 16 * C * 9; i += 256) s_w[conv_w_slot(i)] = P[a.off.conv_w + i];
     if (tid < 16) s_b[tid] = P[a.off.conv_b + tid];
     __syncthreads();
     conv_embed_rows(s_obs, s_w, s_b, C, dst, tid, 256);

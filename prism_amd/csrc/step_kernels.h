@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ float s_scratch[256];
     __shared__ float s_obs[2][1000];
-    __shared__ float s_w[2][16 * 10 * 9];
+    __shared__ __attribute__((aligned(16))) float s_w[2][16 * 10 * CONV_W_PAD];
     __shared__ float s_b[2][16];
     __shared__ int64_t s_i64[2];
     __shared__ float2 s_sibrec[TREE_MAX_LEVELS];
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     for (int k = 0; k < 6; ++k) {
         const int i = tid + 256 * k;
         if (i < nw) {
-            s_w[0][i] = wr[0][k];
-            s_w[1][i] = wr[1][k];
+            s_w[0][conv_w_slot(i)] = wr[0][k];
+            s_w[1][conv_w_slot(i)] = wr[1][k];
         }
     }
     if (tid < 16) {
