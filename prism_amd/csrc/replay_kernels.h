@@ -96,12 +96,27 @@ __device__ __forceinline__ float2 tree_query_fetch(const float2 *__restrict__ v,
     return val;
 }
 __device__ __forceinline__ float2 tree_query_fold(const float *scratch, int64_t cap) {
-    const int used = 2 * (64 - __clzll((unsigned long long)cap));
+    // Slots of levels above the root hold the identities (+0.0f / FLT_MAX), which fold as exact no-ops,
+    // so a fixed number of slots is folded: all of them are fetched as 16-byte words first (one LDS
+    // round trip instead of one per slot), then walked in the sequential order.
+    constexpr int N4 = (2 * (24 + 1) + 3) / 4;                   // 2 * (TREE_MAX_LEVELS + 1) slots
+    (void)cap;
+    const float4 *s4 = reinterpret_cast<const float4 *>(scratch), *m4 = reinterpret_cast<const float4 *>(scratch + 128);
+    float4 sv[N4], mv[N4];
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        sv[i] = s4[i];
+        mv[i] = m4[i];
+    }
     float s = 0.0f, m = FLT_MAX;
-    for (int i = 0; i < used && i < 128; ++i) {
-        s = s + scratch[i];
-        const float c = scratch[128 + i];
-        m = m < c ? m : c;
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        s = ((s + sv[i].x) + sv[i].y);
+        s = ((s + sv[i].z) + sv[i].w);
+        m = m < mv[i].x ? m : mv[i].x;
+        m = m < mv[i].y ? m : mv[i].y;
+        m = m < mv[i].z ? m : mv[i].z;
+        m = m < mv[i].w ? m : mv[i].w;
     }
     return make_float2(s, m);
 }

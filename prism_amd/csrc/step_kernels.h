@@ -87,7 +87,7 @@ struct FrontArgs {
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
 __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
-    __shared__ float s_scratch[256];
+    __shared__ __attribute__((aligned(16))) float s_scratch[256];
     __shared__ float s_obs[2][1000];
     __shared__ __attribute__((aligned(16))) float s_w[2][16 * 10 * CONV_W_PAD];
     __shared__ float s_b[2][16];
@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= B) {
+        PRISM_STAMP(27);
         front_extra_block(a, b - B, s_scratch);
+        PRISM_STAMP(31);
         return;
     }
     PRISM_STAMP(27);
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
             s_scratch[128 + tid] = qv.y;
         }
         __syncthreads();
+        PRISM_STAMP(24);
         if (tid == 0) {
             const float2 pq = tree_query_fold(s_scratch, cap);
             const float p_sum = pq.x, p_min = pq.y;

@@ -44,6 +44,11 @@ B = cfg.batch_size
 fr = s[:B, 27:32].astype(np.float64)
 if fr[:, 0].any():
     print("front sample blocks (top+query | descent | n-step | gather+conv): med", [int(np.median(fr[:, k + 1] - fr[:, k])) for k in range(4)], "total", int(np.median(fr[:, 4] - fr[:, 0])))
+ft = s[:B, [27, 24, 28]].astype(np.float64)
+if ft[:, 1].any(): print("   top+query detail (loads + LDS staging + barrier | p_sum/p_min fold by lane 0):", [int(np.median(ft[:, k + 1] - ft[:, k])) for k in range(2)])
+fx = s[B:B + 1024, [27, 31]].astype(np.float64)
+fx = fx[fx[:, 0] != 0]
+if len(fx): print(f"front extra blocks (u/v, weight packing): n={len(fx)} dur med {int(np.median(fx[:, 1] - fx[:, 0]))} max {int(np.max(fx[:, 1] - fx[:, 0]))}")
 # post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
 n_conv = 1 if (cfg.use_iqn and not cfg.use_ids and not cfg.use_dqn) else (B + 3) // 4
 pb = s[:, 13] != 0
