@@ -254,11 +254,21 @@ __device__ __forceinline__ void tile_trunk_head(const IqnArgs &a, const TrunkPar
     const int li = lane & 15, g = lane >> 4;
     const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
     float4 lng[4], lnb[4];      // LayerNorm(1024) affine for this lane's 16 columns: in flight across the barrier
+    if (((reinterpret_cast<uintptr_t>(tp.ln1_g) | reinterpret_cast<uintptr_t>(tp.ln1_b)) & 15) == 0) {
+        // (IQN trunk: 16-byte aligned -- a quarter of the address traffic of the scalar form, which
+        // competes with the weight stream for the same address path)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float *pg = tp.ln1_g + (i * 64 + lane) * 4, *pb = tp.ln1_b + (i * 64 + lane) * 4;
-        lng[i] = float4{pg[0], pg[1], pg[2], pg[3]};     // head tensors are only 4-byte aligned
-        lnb[i] = float4{pb[0], pb[1], pb[2], pb[3]};
+        for (int i = 0; i < 4; ++i) {
+            lng[i] = reinterpret_cast<const float4 *>(tp.ln1_g)[i * 64 + lane];
+            lnb[i] = reinterpret_cast<const float4 *>(tp.ln1_b)[i * 64 + lane];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *pg = tp.ln1_g + (i * 64 + lane) * 4, *pb = tp.ln1_b + (i * 64 + lane) * 4;
+            lng[i] = float4{pg[0], pg[1], pg[2], pg[3]};     // head tensors are only 4-byte aligned
+            lnb[i] = float4{pb[0], pb[1], pb[2], pb[3]};
+        }
     }
     lds_barrier();
 
