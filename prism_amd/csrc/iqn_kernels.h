@@ -1309,11 +1309,13 @@ constexpr int SMALL_W = 16;
 constexpr int SMALL_GROUP = 8;                                   // per-unit sums folded per LDS pass
 constexpr int SMALL_POOL_FLOATS = SMALL_GROUP * 64 * 17;
 struct SmallIo {
-    const float *w2, *g2, *be2, *b1, *b2;   // parameters of the head (b1, b2 only read with kappa)
-    float *gw2, *gg2, *gbe2, *gb1, *gb2;    // their gradients
+    const float *w2, *g2, *be2, *b1, *b2;   // parameters of the head (b1, b2 only read with kappa); g2 == NULL:
+                                            // no affine in front of the Linear (g = 1, beta = 0, no dg / dbeta)
+    float *gw2, *gg2, *gbe2, *gb1, *gb2;    // their gradients (gb1 == NULL: no b1 row)
     float kappa;
     bool use_kappa;
     const float *extra;                     // optional [B]: slice 0 leaves sum_b extra[b] in *extra_sum (thread 0)
+    int w_stride;                           // row stride of w2 / gw2 (units per action row)
 };
 // load(b, h, want_d) -> {v, p, d}
 template <typename Load>
@@ -1329,12 +1331,12 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
     const int ta = tid >> 4;
     float w2 = 0.f, g2 = 0.f, be2 = 0.f, b1v = 0.f, b2v = 0.f;
     if (ta < A) {
-        w2 = io.w2[ta * H_DIM + h];
-        g2 = io.g2[h];
-        be2 = io.be2[h];
+        w2 = io.w2[(int64_t)ta * io.w_stride + h];
+        g2 = io.g2 ? io.g2[h] : 1.f;
+        be2 = io.g2 ? io.be2[h] : 0.f;
     }
     if (io.use_kappa) {
-        if (tid >= 2 * SMALL_W && tid < 3 * SMALL_W) b1v = io.b1[h];
+        if (io.gb1 && tid >= 2 * SMALL_W && tid < 3 * SMALL_W) b1v = io.b1[h];
         if (slice == 0 && tid < A) b2v = io.b2[tid];
     }
     float sA[16], dA[16];
@@ -1399,7 +1401,7 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
         const float S = s_S[ta][hl], D = s_D[ta];
         float dw = g2 * S + be2 * D;
         if (io.use_kappa) dw += k * w2;
-        io.gw2[ta * H_DIM + h] = dw;
+        io.gw2[(int64_t)ta * io.w_stride + h] = dw;
         sq += dw * dw;
         dg = w2 * S;
         db = w2 * D;
@@ -1410,13 +1412,15 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
     }
     __syncthreads();
     if (tid < 2 * SMALL_W) {                 // threads [0,16): d ln2_g; [16,32): d ln2_b
-        const int which = tid >> 4;
-        float t = 0.f;
-        for (int aa = 0; aa < A; ++aa) t += s_dgb[which][aa][hl];
-        if (io.use_kappa) t += k * (which ? io.be2[h] : io.g2[h]);
-        (which ? io.gbe2 : io.gg2)[h] = t;
-        sq += t * t;
-    } else if (tid < 3 * SMALL_W) {
+        if (io.g2) {
+            const int which = tid >> 4;
+            float t = 0.f;
+            for (int aa = 0; aa < A; ++aa) t += s_dgb[which][aa][hl];
+            if (io.use_kappa) t += k * (which ? io.be2[h] : io.g2[h]);
+            (which ? io.gbe2 : io.gg2)[h] = t;
+            sq += t * t;
+        }
+    } else if (tid < 3 * SMALL_W && io.gb1) {
         float t = s_S[A][hl];
         if (io.use_kappa) t += k * b1v;
         io.gb1[h] = t;
@@ -1443,7 +1447,7 @@ __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, 
     float *gr = a.grads;
     SmallIo io{P + a.off.iqn_w2, P + a.off.iqn_ln2_g, P + a.off.iqn_ln2_b, P + a.off.iqn_b1, P + a.off.iqn_b2,
                gr + a.off.iqn_w2, gr + a.off.iqn_ln2_g, gr + a.off.iqn_ln2_b, gr + a.off.iqn_b1, gr + a.off.iqn_b2,
-               0.f, false, a.ws.lossw};
+               0.f, false, a.ws.lossw, H_DIM};
     float lsum = 0.f;
     small_fold_block(a, slice, sq, pool, io,
                      [&](int b, int h, bool want_d) {

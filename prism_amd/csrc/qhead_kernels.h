@@ -349,7 +349,7 @@ __device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, i
     float *Gh = a.grads + a.off.head_base + (int64_t)hd * a.off.head_stride;
     SmallIo io{Ph + a.off.h_w2, Ph + a.off.h_ln2_g, Ph + a.off.h_ln2_b, Ph + a.off.h_b1, Ph + a.off.h_b2,
                Gh + a.off.h_w2, Gh + a.off.h_ln2_g, Gh + a.off.h_ln2_b, Gh + a.off.h_b1, Gh + a.off.h_b2,
-               kappa ? kappa[hd] : 0.f, kappa != nullptr, nullptr};
+               kappa ? kappa[hd] : 0.f, kappa != nullptr, nullptr, H_DIM};
     const int64_t r0 = (int64_t)hd * a.B;
     small_fold_block(a, slice, sq, pool, io,
                      [&](int b, int h, bool) {
@@ -533,95 +533,34 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
 }
 
 // post role: dW[a][n] = sum_{b: act=a} dq_b * y_b[n], db[a], and with LayerNorm dg[n] = sum_b dy_b[n] xhat_b[n],
-// dbeta[n] = sum_b dy_b[n] (dy_b = dq_b W[act_b]).  1024 threads = 128 columns x 8 batch parts; 8 blocks.
-constexpr int DQN_GRAD_BLOCKS = E_DIM / 128;
+// dbeta[n] = sum_b dy_b[n] (dy_b = dq_b W[act_b]).  With y = g * xhat + beta this is the algebra of
+// small_fold_block with the 1024 embedding columns as "units":
+//   S[a][n] = sum_{b: act=a} dq_b xhat_b[n],  D[a] = sum_{b: act=a} dq_b,
+//   dW = g S + beta D,  dg = sum_a W S,  dbeta = sum_a W D,  db = D        (no LayerNorm: xhat := e, g = 1, beta = 0)
+// 16 columns per workgroup -> E/16 workgroups; slice 0 also writes db and the total loss.
+constexpr int DQN_GRAD_BLOCKS = E_DIM / SMALL_W;
 
-__device__ __forceinline__ void dqn_grad_block(const IqnArgs &a, int slice, float &sq) {
-    __shared__ float s_part[8][128];
-    const int tid = threadIdx.x, B = a.B, A = a.A;
-    const int nl = tid & 127, part = tid >> 7, n = slice * 128 + nl;
+__device__ __forceinline__ void dqn_grad_block(const IqnArgs &a, int slice, float &sq, float *pool) {
     const bool ln = a.off.h_ln1_g >= 0;
     const float *P = a.params + a.off.head_base;
     float *G = a.grads + a.off.head_base;
-    const float gn = ln ? P[a.off.h_ln1_g + n] : 1.f, bn = ln ? P[a.off.h_ln1_b + n] : 0.f;
-    float sA[16];
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa) sA[aa] = 0.f;
-    float dgs = 0.f, dbs = 0.f;
-#pragma unroll 4
-    for (int b = part; b < B; b += 8) {
-        const float dq = a.ws.q_dq[b];
-        const int ab = (int)a.action[b];
-        const float e = a.ws.e_cur[(int64_t)b * E_DIM + n];
-        float y = e;
-        if (ln) {
-            const float xh = (e - a.ws.q_mu1[b]) * a.ws.q_rstd1[b];
-            y = xh * gn + bn;
-            const float dy = dq * P[a.off.h_w1 + (int64_t)ab * E_DIM + n];
-            dgs += dy * xh;
-            dbs += dy;
-        }
-        const float v = dq * y;
-#pragma unroll
-        for (int aa = 0; aa < 16; ++aa) sA[aa] += (ab == aa) ? v : 0.f;
-    }
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa) {
-        if (aa < A) {
-            __syncthreads();
-            s_part[part][nl] = sA[aa];
-            __syncthreads();
-            if (part == 0) {
-                float t = 0.f;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) t += s_part[p][nl];
-                G[a.off.h_w1 + (int64_t)aa * E_DIM + n] = t;
-                sq += t * t;
-            }
-        }
-    }
-    if (ln) {
-        __syncthreads();
-        s_part[part][nl] = dgs;
-        __syncthreads();
-        if (part == 0) {
-            float t = 0.f;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) t += s_part[p][nl];
-            G[a.off.h_ln1_g + n] = t;
-            sq += t * t;
-        }
-        __syncthreads();
-        s_part[part][nl] = dbs;
-        __syncthreads();
-        if (part == 0) {
-            float t = 0.f;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) t += s_part[p][nl];
-            G[a.off.h_ln1_b + n] = t;
-            sq += t * t;
-        }
-    }
-    if (slice == 0) {
-        // db[a] = sum_{b: act=a} dq_b (one wave per action), total loss = mean(ql * w)
-        const int aa = tid >> 6, lane = tid & 63;
-        float s = 0.f, lw = 0.f;
-        if (aa < A)
-            for (int b = lane; b < B; b += 64) s += ((int)a.action[b] == aa) ? a.ws.q_dq[b] : 0.f;
-        if (aa == 15)
-            for (int b = lane; b < B; b += 64) lw += a.ws.q_lossw[b];
-        s = wave_sum(s);
-        lw = wave_sum(lw);
-        if (lane == 0 && aa < A) {
-            G[a.off.h_b1 + aa] = s;
-            sq += s * s;
-        }
-        if (lane == 0 && aa == 15) {
-            const float l = lw / (float)B;
-            a.out_scalars[0] = l;
-            a.out_scalars[1] = 0.f;
-            a.out_scalars[2] = l;
-        }
+    SmallIo io{P + a.off.h_w1, ln ? P + a.off.h_ln1_g : nullptr, ln ? P + a.off.h_ln1_b : nullptr, nullptr, P + a.off.h_b1,
+               G + a.off.h_w1, ln ? G + a.off.h_ln1_g : nullptr, ln ? G + a.off.h_ln1_b : nullptr, nullptr, G + a.off.h_b1,
+               0.f, false, a.ws.q_lossw, E_DIM};
+    float lsum = 0.f;
+    small_fold_block(a, slice, sq, pool, io,
+                     [&](int b, int n, bool) {
+                         const float dq = a.ws.q_dq[b];
+                         float x = a.ws.e_cur[(int64_t)b * E_DIM + n];
+                         if (ln) x = (x - a.ws.q_mu1[b]) * a.ws.q_rstd1[b];
+                         return make_float3(dq * x, 0.f, dq);
+                     },
+                     &lsum);
+    if (slice == 0 && threadIdx.x == 0) {
+        const float l = lsum / (float)a.B;          // total loss = mean(ql * w)
+        a.out_scalars[0] = l;
+        a.out_scalars[1] = 0.f;
+        a.out_scalars[2] = l;
     }
 }
 

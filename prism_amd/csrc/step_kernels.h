@@ -404,7 +404,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             }
         }
         if (!done && a.head_layers == 1) {
-            dqn_grad_block(a, blk, sq);
+            dqn_grad_block(a, blk, sq, reinterpret_cast<float *>(s_pool));
             done = true;
         }
         if (!done) {
