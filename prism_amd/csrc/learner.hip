@@ -210,7 +210,9 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     {
         const size_t post_rows = (size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW;
         const size_t bwd_rows = (size_t)(E_DIM / 16) * N_CHUNKS * BWD_CONV_ROW;
-        w.convpart = c.f(post_rows > bwd_rows ? post_rows : bwd_rows);
+        const size_t dqn_rows = d->head_layers == 1 && d->n_heads ? (size_t)B * CONV_ROW : 0;   // one row per sample
+        const size_t m = post_rows > bwd_rows ? post_rows : bwd_rows;
+        w.convpart = c.f(m > dqn_rows ? m : dqn_rows);
     }
     w.normpart = c.f(NORM_SLOTS);
     w.sib = c.f((size_t)TREE_MAX_LEVELS * B * 2);
@@ -302,7 +304,7 @@ static int loss_in_fwd(const prism_model_dims &d) {
 
 static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
-    if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(ld->batch);
+    if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(d.in_channels);
     return post_blocks(ld->batch, d.use_iqn, d.n_heads,
                        bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS));
 }

@@ -425,19 +425,60 @@ __device__ __forceinline__ void dqn_layernorm(float *s_x, float *s_xhat, const f
     __syncthreads();
 }
 
+// conv-backward partial row of ONE sample (the block that just produced d e of that sample has everything
+// at hand): out[c*9C + ci*9 + dy*3 + dx] = sum_{y,x} dc[c][y][x] * obs[y+dy][x+dx][ci], out[16*9C + c] = sum dc[c].
+// s_dc: ReLU-masked d e [1024] (channel-major), s_ob: the observation [100*C]; 256 threads.
+__device__ __forceinline__ void conv_bwd_sample_row(const float *s_dc, const float *s_ob, int C, float *__restrict__ out) {
+    const int tid = threadIdx.x, nk = 9 * C;
+    // work item = (out channel c, in channel ci, kernel row dy): its three dx outputs share every operand
+    // (8 gradient + 10 observation values of an image row feed 24 MACs in three independent chains)
+    for (int item = tid; item < 16 * C * 3; item += 256) {
+        const int c = item / (3 * C), r = item - c * 3 * C, ci = r / 3, dy = r - ci * 3;
+        const float *dc = s_dc + c * 64, *ob = s_ob + dy * 10 * C + ci;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            const float4 d0 = *reinterpret_cast<const float4 *>(dc + y * 8), d1 = *reinterpret_cast<const float4 *>(dc + y * 8 + 4);
+            const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float row[10];
+#pragma unroll
+            for (int x = 0; x < 10; ++x) row[x] = ob[(y * 10 + x) * C];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                a0 = fmaf(d[x], row[x], a0);
+                a1 = fmaf(d[x], row[x + 1], a1);
+                a2 = fmaf(d[x], row[x + 2], a2);
+            }
+        }
+        float *o = out + c * nk + ci * 9 + dy * 3;
+        o[0] = a0;
+        o[1] = a1;
+        o[2] = a2;
+    }
+    const int w = tid >> 6, lane = tid & 63;
+    for (int c = w; c < 16; c += 4) {
+        const float s = wave_sum(s_dc[c * 64 + lane]);
+        if (lane == 0) out[16 * nk + c] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
-    __shared__ float s_x[E_DIM], s_xhat[E_DIM], s_nx[E_DIM], s_tmp[E_DIM];
+    __shared__ __attribute__((aligned(16))) float s_x[E_DIM], s_xhat[E_DIM], s_nx[E_DIM], s_tmp[E_DIM];
+    __shared__ float s_ob[1000];
     __shared__ float s_q[16], s_qo[16], s_qt[16], s_red[64];
     __shared__ float s_sc[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A;
     const bool ln = a.off.h_ln1_g >= 0;
     const float *P = a.params + a.off.head_base, *Pt = (a.has_target ? a.target_params : a.params) + a.off.head_base;
+    float ec[4];                                         // conv output of this sample (ReLU mask of the tail)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        s_x[tid + 256 * i] = a.ws.e_cur[(int64_t)b * E_DIM + tid + 256 * i];
+        ec[i] = a.ws.e_cur[(int64_t)b * E_DIM + tid + 256 * i];
+        s_x[tid + 256 * i] = ec[i];
         s_nx[tid + 256 * i] = a.ws.e_next[(int64_t)b * E_DIM + tid + 256 * i];
     }
+    for (int i = tid; i < 100 * a.C; i += 256) s_ob[i] = a.obs[(int64_t)b * 100 * a.C + i];   // for the conv-backward tail
     __syncthreads();
     float mean = 0.f, rstd = 1.f;
     if (ln) dqn_layernorm(s_x, s_xhat, P + a.off.h_ln1_g, P + a.off.h_ln1_b, mean, rstd, s_red);
@@ -522,14 +563,19 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
         const float m1 = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) * (1.0f / E_DIM);
         const float m2 = ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])) * (1.0f / E_DIM);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = tid + 256 * i;
-            a.ws.de_q[(int64_t)b * E_DIM + n] = rstd * (dxh[i] - m1 - s_xhat[n] * m2);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a.ws.de_q[(int64_t)b * E_DIM + tid + 256 * i] = dy[i];
+        for (int i = 0; i < 4; ++i) dy[i] = rstd * (dxh[i] - m1 - s_xhat[tid + 256 * i] * m2);
     }
+    // d e of this sample -> workspace; its ReLU-masked copy feeds the conv-backward partial row right here
+    // (one row per sample, folded by the post kernel: no partial/ticket/fold chain there)
+    __syncthreads();                                     // s_tmp (next-state scratch) is free
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = tid + 256 * i;
+        a.ws.de_q[(int64_t)b * E_DIM + n] = dy[i];
+        s_tmp[n] = ec[i] > 0.f ? dy[i] : 0.f;
+    }
+    __syncthreads();
+    conv_bwd_sample_row(s_tmp, s_ob, a.C, a.ws.convpart + (int64_t)b * CONV_ROW);
 }
 
 // post role: dW[a][n] = sum_{b: act=a} dq_b * y_b[n], db[a], and with LayerNorm dg[n] = sum_b dy_b[n] xhat_b[n],

@@ -259,8 +259,10 @@ __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool
     if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_QSMALL_BLOCKS;
     return n;
 }
-__host__ __device__ inline int post_blocks_dqn1(int B) { return (B + CONV_SPB - 1) / CONV_SPB + DQN_GRAD_BLOCKS;
-}
+// one-layer DQN head: the loss kernel leaves one conv partial row per sample; CONV_FOLD_W outputs per fold block
+constexpr int CONV_FOLD_W = 64;
+__host__ __device__ inline int dqn1_conv_blocks(int C) { return (16 * 9 * C + 16 + CONV_FOLD_W - 1) / CONV_FOLD_W; }
+__host__ __device__ inline int post_blocks_dqn1(int C) { return dqn1_conv_blocks(C) + DQN_GRAD_BLOCKS; }
 
 __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     const int tid = threadIdx.x;
@@ -314,10 +316,30 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     __shared__ float s_kappa[Q_MAX_HEADS];
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
-    const int n_conv = a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
+    const bool dqn1 = a.head_layers == 1 && a.n_heads;
+    const int n_conv = dqn1 ? dqn1_conv_blocks(C) : (a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB);
     int blk = blockIdx.x;
     float sq = 0.f;
-    if (a.conv_in_bwd && blk == 0) {
+    if (dqn1 && blk < n_conv) {
+        // fold the per-sample rows of the loss kernel: 64 outputs x 16 batch parts per workgroup
+        float *s_part = reinterpret_cast<float *>(s_pool);           // [16][CONV_FOLD_W]
+        const int nk = 9 * C, n_out = 16 * nk + 16;
+        const int ol = tid & (CONV_FOLD_W - 1), part = tid >> 6, o = blk * CONV_FOLD_W + ol;
+        float t = 0.f;
+        if (o < n_out) {
+#pragma unroll 16
+            for (int b = part; b < B; b += 16) t += a.ws.convpart[(int64_t)b * CONV_ROW + o];
+        }
+        s_part[part * CONV_FOLD_W + ol] = t;
+        __syncthreads();
+        if (part == 0 && o < n_out) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += s_part[q * CONV_FOLD_W + ol];
+            a.grads[(o < 16 * nk ? a.off.conv_w : a.off.conv_b - 16 * nk) + o] = v;
+            sq += v * v;
+        }
+    } else if (a.conv_in_bwd && blk == 0) {
         // the backward kernel left one partial row per (row chunk rc, column slice cs): channel c owns
         // slices 4c..4c+3.  Fold them in fixed order (rc outer, slice inner).
         const int nk = 9 * C, n_out = 16 * nk + 16, n_cs = E_DIM / 16;
