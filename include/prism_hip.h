@@ -224,7 +224,7 @@ typedef struct prism_learner_desc {
     float *out_td;            /* [B]          (td_errors, composite_model.py:135-142)         */
     float *out_scalars;       /* [8] {total loss, mean dl*w, mean ql*w, grad norm, theil, clip coef, -, -} */
     float *dbg_z;             /* optional [ (T+T')*B*A ] quantile estimates (tests) or NULL    */
-    void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][32] uint64 shader-clock stamps, else NULL */
+    void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][64] uint64 shader-clock stamps, else NULL */
     void *workspace;          /* >= prism_learner_workspace_bytes()                           */
     size_t workspace_bytes;
     prism_adam_hyper hyper;

@@ -224,7 +224,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 #define PRISM_STAMP(k)                                                                     \
     do {                                                                                   \
-        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // ------------------------------------------------------------------------------------------
@@ -844,13 +844,12 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
     // Launch order puts every publisher at a lower workgroup index than its consumer, so a waiting
     // consumer never holds a CU that its publisher still needs.
     __syncthreads();                     // all rows of this tile are out (the barrier waits for vmcnt(0))
-    PRISM_STAMP(16);
+    PRISM_STAMP(32);
     if (ps.loss_role == 1) {
         if (tid == 0) __hip_atomic_fetch_add(&a.ws.loss_flag[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (ps.loss_role == 2) {
-        PRISM_STAMP(17);
         iqn_loss_tile(a, r0, smem, &a.ws.loss_flag[tile], (unsigned)a.loss_in_fwd);
-        PRISM_STAMP(18);
+        PRISM_STAMP(33);
     }
 }
 

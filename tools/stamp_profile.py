@@ -14,23 +14,22 @@ with contextlib.redirect_stdout(io.StringIO()):
 fill_replay(ln.experience_buffer, 20000 if cfg.experience_replay_capacity > 20000 else cfg.experience_replay_capacity, seed=0)
 ag = ln.agent
 for _ in range(5): ln.step(eager=True)
-st = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda:0")
+st = torch.zeros(4096 * 64, dtype=torch.int64, device="cuda:0")
 ag._desc.dbg_stamps = st.data_ptr()
 # tile_fwd and bwd share the stamp buffer: run one step, read after each kernel is impossible -> use
 # the fact that bwd overwrites slots 0..4 of its own blocks; dump both by running twice with masks
 def run():
-    st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 32)
+    st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 64)
 s = run()
 f = s[:256, :8].astype(np.float64)
-names = ["wphi issue+row setup", "cos+barrier", "phi mfma+ytile", "w1 issue+barrier", "layernorm", "trunk mfma", "fold", "ln128+head"]
+names = ["weights issue, tau, cos basis", "phi GEMM (K=64) + epilogue", "barrier", "LayerNorm(1024)", "trunk GEMM (K=1024)", "fold of the K slices", "LayerNorm(128) + head"]
 print("tile_fwd (median over 256 workgroups, shader-clock ticks):")
 for k in range(7):
     print(f"   {names[k]:24s} {np.median(f[:, k + 1] - f[:, k]):9.0f}")
 print(f"   total {np.median(f[:, 7] - f[:, 0]):9.0f}   start spread {f[:, 0].max() - f[:, 0].min():9.0f}   end spread {f[:, 7].max() - f[:, 7].min():9.0f}")
-ow = s[128:256, [7, 16, 17, 18, 19]].astype(np.float64)
-if ow[:, 2].any(): print("   fused loss tail of the current-state tiles (barrier | wait | sample 0 | sample 1):", [int(np.median(ow[:, k + 1] - ow[:, k])) for k in range(4)])
-lw = s[128:256, [18, 20, 21, 22, 23, 19]].astype(np.float64)
-if lw[:, 1].any(): print("   loss of sample 1 (loads+stage | argmax | huber | LN backward | reduce+store):", [int(np.median(lw[:, k + 1] - lw[:, k])) for k in range(5)])
+ow = s[s[:, 33] != 0][:, [7, 32, 33]].astype(np.float64)
+n_pub = int((s[:, 32] != 0).sum()) - len(ow)
+if len(ow): print("   fused loss tail of the current-state tiles (barrier | loss of the tile's samples, incl. the wait for the publishers):", [int(np.median(ow[:, k + 1] - ow[:, k])) for k in range(2)], f"({len(ow)} consumer tiles, {n_pub} publisher tiles)")
 nb = int((s[:, 8] != 0).sum())
 b = s[:nb, 8:13].astype(np.float64)
 print(f"bwd ({nb} workgroups):")
