@@ -130,13 +130,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # PRISM_BENCH_REHEARSAL=1: run the N > 1 code path with all ranks on GPU 0 and gloo over host memory
+    # (a one-GPU box cannot host two RCCL ranks); the numbers mean nothing, the control flow is the point
+    rehearsal = os.environ.get("PRISM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearsal:
+            dist.init_process_group("gloo")
+            from prism_amd import dist as pdist
+
+            def host_allreduce(flat, group=None):
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                flat.copy_(h)
+                return 1.0 / dist.get_world_size(group)
+            pdist.allreduce_grads = host_allreduce
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
         pg = dist.group.WORLD
 
     from prism_amd import _native as N
@@ -189,7 +205,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     L.prism_profile_collect(ms, cnt)
