@@ -285,3 +285,46 @@ def test_interleaved_env_chains_wrap_the_ring(dev, cap, n_env, total, seed):
     np.testing.assert_array_equal(buf.link.cpu().numpy(), orc.link)
     np.testing.assert_array_equal(buf.flags.cpu().numpy(), orc.flags)
     np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), orc.sampler.sum_tree.values())
+
+
+@pytest.mark.parametrize("capacity,B", [(1000, 256), (5000, 512), (70_000, 64)])
+def test_tree_invariants_and_monotone_sampling(dev, capacity, B):
+    """Size-independent properties of the device trees after many writebacks with heavy duplication:
+    every parent is fl32(left + right) / min(left, right) of its children, the root is the total mass,
+    duplicate indices resolve to the LAST occurrence, and the sampled index is monotone in the mass."""
+    import ctypes
+    from prism_amd import _native as Nn
+    buf = _mk_buffer(dev, capacity, B, use_per=True)
+    rng = np.random.default_rng(capacity)
+    O = 400
+    buf.load_arrays(np.zeros((capacity, 10, 10, 4), np.float32), np.zeros((capacity, O), np.float32),
+                    np.zeros(capacity, np.float32), np.zeros(capacity, np.int32), np.zeros(capacity, np.uint8),
+                    np.full(capacity, -1, np.int32), priorities=np.full(capacity, 1.0, np.float32))
+    last = {}
+    for it in range(20):
+        # a third of the batch hits only 8 distinct slots: many duplicates per call
+        idx = np.where(rng.random(B) < 0.33, rng.integers(0, 8, B), rng.integers(0, capacity, B)).astype(np.int64)
+        td = (rng.random(B) * 5).astype(np.float32)
+        buf.update_priority(torch.from_numpy(idx).to(dev), torch.from_numpy(td).to(dev))
+        for i, t in zip(idx, td):
+            last[int(i)] = t
+    torch.cuda.synchronize()
+    tree = buf.tree.cpu().numpy()
+    cap2 = buf.tree_capacity
+    s, m = tree[:, 0], tree[:, 1]
+    par = np.arange(1, cap2)
+    np.testing.assert_array_equal(s[par], s[2 * par] + s[2 * par + 1])
+    np.testing.assert_array_equal(m[par], np.minimum(m[2 * par], m[2 * par + 1]))
+    for i, t in last.items():                                   # last occurrence wins, (|td| + eps) ** alpha
+        want = np.float32(np.sqrt(np.float32(t) + np.float32(1e-8)))
+        assert s[cap2 + i] == want and m[cap2 + i] == want, i
+    # monotone: ascending masses -> non-decreasing indices, all inside [0, size)
+    mass = np.sort(rng.random(B).astype(np.float32)) * np.float32(s[1])
+    mt = torch.from_numpy(mass).to(dev)
+    with torch.cuda.device(dev):
+        Nn.check(Nn.lib().prism_per_sample(ctypes.byref(buf._desc), capacity, B, Nn.ptr(mt), 0, 0, 0.5,
+                                           Nn.ptr(buf._index), Nn.ptr(buf._weight), Nn.current_stream_handle()), "sample")
+    torch.cuda.synchronize()
+    got = buf._index.cpu().numpy()
+    assert (np.diff(got) >= 0).all() and got.min() >= 0 and got.max() < capacity
+    assert abs(float(s[1]) - float(np.sum(s[cap2:cap2 + capacity], dtype=np.float64))) < 1e-3 * float(s[1])
