@@ -328,3 +328,29 @@ def test_tree_invariants_and_monotone_sampling(dev, capacity, B):
     got = buf._index.cpu().numpy()
     assert (np.diff(got) >= 0).all() and got.min() >= 0 and got.max() < capacity
     assert abs(float(s[1]) - float(np.sum(s[cap2:cap2 + capacity], dtype=np.float64))) < 1e-3 * float(s[1])
+
+
+def test_full_size_shard_properties(dev):
+    """BASELINE configs[4] shard size (1.25 M slots, cap2 = 2^21): a full learner-sized writeback
+    (B = 512, duplicates included) keeps every parent equal to op(children), checked on the device."""
+    from prism_amd.synthetic import fill_replay
+    capacity, B = 1_250_000, 512
+    buf = _mk_buffer(dev, capacity, B, use_per=True)
+    fill_replay(buf, capacity, seed=1)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    for _ in range(8):
+        idx = torch.randint(0, capacity, (B,), device=dev, generator=g)
+        idx[:64] = idx[64:128]                                   # duplicates
+        td = torch.rand(B, device=dev, generator=g) * 3
+        buf.update_priority(idx, td)
+    batch, info = buf.sample(return_info=True)
+    torch.cuda.synchronize()
+    t, cap2 = buf.tree, buf.tree_capacity
+    kids = t[2:2 * cap2].view(cap2 - 1, 2, 2)                    # node p -> children 2p, 2p+1
+    assert torch.equal(t[1:cap2, 0], kids[:, 0, 0] + kids[:, 1, 0])
+    assert torch.equal(t[1:cap2, 1], torch.minimum(kids[:, 0, 1], kids[:, 1, 1]))
+    idx = info["index"]
+    assert int(idx.min()) >= 0 and int(idx.max()) < capacity
+    w = info["_weight"]
+    assert float(w.max()) <= 1.0 + 1e-6 and float(w.min()) > 0.0
