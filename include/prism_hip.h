@@ -246,9 +246,11 @@ int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream);
 int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused hot path — one Learner iteration (prism/learner.py:95-125) in six launches:
+ * Fused hot path — one Learner iteration (prism/learner.py:95-125) in five launches (IQN; one or two
+ * more with Q heads):
  *   prism_step_front                        PER sample + n-step gather + conv embed (+ LayerNorm helpers)
- *   prism_learner_fwd_bwd (embed_done = 1)  quantile forward tiles, loss, column-sliced backward, post
+ *   prism_learner_fwd_bwd (embed_done = 1)  quantile forward tiles with the loss in their tail, column-sliced
+ *                                           backward, post (gradient reduction + first half of the writeback)
  *   [RCCL all-reduce of ld->grads when data-parallel]
  *   prism_step_back                         clip + Adam, priority writeback with |td|, RNG counters
  * Results are identical to per_sample -> replay_gather -> fwd_bwd -> clip_adam -> per_update.

@@ -1,20 +1,24 @@
 // IQN TD-update kernels for gfx950 (fp32 MFMA 16x16x4, wave64).
 //
 // Restates /root/reference/prism/agents/models/iqn_model.py:48-201 (+ ffnn_model.py:61-76,
-// minatar_cnn_model.py:43-46) as six launches:
+// minatar_cnn_model.py:43-46) as these kernels and block routines:
 //
 //   embed      conv3x3+ReLU of obs / next_obs -> e_cur, e_next [B,1024]; extra workgroups compute
-//              u = W1 g1, v = W1 beta1 (used to get LayerNorm-backward row sums without dX)
+//              u = W1 g1, v = W1 beta1 (used to get LayerNorm-backward row sums without dX) and repack
+//              the GEMM weights in MFMA-fragment order (in the fused step: part of step_front_kernel)
 //   tile_fwd   one 16-row tile of (sample, tau) rows per workgroup, whole rows on chip:
 //              cos basis -> phi GEMM (K=64) -> ReLU -> Hadamard with e -> LayerNorm(1024) ->
-//              trunk GEMM (K=1024) -> ReLU -> LayerNorm(128) -> head -> Z[16, A]
-//   loss       one wave per sample: argmax / n-step target / pairwise quantile-Huber tile,
+//              trunk GEMM (K=1024) -> ReLU -> LayerNorm(128) -> head -> Z[16, A]; the current-state
+//              tiles then run the loss of their samples (iqn_loss_tile) once the next-state tiles of
+//              the same samples have published their rows
+//   loss       the same loss as a kernel of its own (one workgroup per sample) for shapes where a tile
+//              does not hold whole samples: argmax / n-step target / pairwise quantile-Huber tile,
 //              dL/dq, head + LayerNorm(128) backward -> dpre1 and the per-row scalars
 //   bwd        column-sliced backward: workgroup (16 embed columns x a row chunk) recomputes its
 //              columns of phi / LN from saved row statistics and accumulates dWphi, dW1, dLN, de
-//              with NO cross-workgroup reduction (per-chunk slabs)
-//   small      conv-backward partials + the small tensors (b1, LN2, W2, b2)
-//   reduce     slabs/partials -> flat gradient + sum-of-squares partials
+//              with NO cross-workgroup reduction (per-chunk slabs); IQN-only models: conv-backward taps
+//   post roles conv-backward partials / fold, the small tensors (b1, LN2, W2, b2), slab sums -> flat
+//              gradient + sum-of-squares partials (iqn_post_kernel in step_kernels.h)
 //
 // Rows are SAMPLE-major inside the workspace (row = b*T + t); the reference's tau-major order
 // (row = t*B + b, iqn_model.py:70) only matters for how tau inputs are indexed.
@@ -568,7 +572,6 @@ __device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *l
     const int wps = T / 2;                       // waves per sample (8 waves x 2 rows = 16 rows)
     const int smp = (2 * w) / T;                 // local sample of this wave
     const int b = r0 / T + smp;
-    const int t0 = 2 * w - smp * T;              // this wave's rows are quantiles t0, t0 + 1 of sample b
     float xa[2], xb[2], pa[2], pb[2], rs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -678,7 +681,6 @@ __device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *l
         Pbb += gb;
         Dsum += dq;
     }
-    (void)t0;
     s_acc[w][lane] = Sa;
     s_acc[w][64 + lane] = Sbb;
     s_acc[w][128 + lane] = Pa;
@@ -893,9 +895,6 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
            9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE4 * 64 &&
            (BWD_MAIN_LDS + bwd_conv_lds_floats(B, C, n_chunks)) * 4 <= 76 * 1024;     // two workgroups per CU
 }
-#ifndef BWD_PREFETCH
-#define BWD_PREFETCH 0
-#endif
 #ifndef BWD_CHUNKS
 #define BWD_CHUNKS 8
 #endif
@@ -970,8 +969,8 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         if (idx < ws_n * 10 * C) reinterpret_cast<float4 *>(s_obs)[idx] = pre4[i];
     }
     PRISM_STAMP(9);
-    // operands of one 16-row tile, fetched one tile ahead of the MFMA work (software prefetch: with a
-    // single wave per SIMD nothing else hides the L2 latency)
+    // operands of one 16-row tile (fetching a tile ahead was tried twice and loses: the registers it
+    // costs matter more than the latency it hides with two workgroups per CU)
     struct TileIn {
         float4 ac[4], ad[8];     // A fragments: cos rows / dpre1 rows (row = r0 + j, k = 16q + 4g + jj)
         float4 mu, rs, c1, c2;   // row scalars of the D-layout rows 4g..4g+3
@@ -1108,27 +1107,11 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
             }
         }
     };
-#if BWD_PREFETCH
-    {
-        TileIn tA, tB;
-        if (tiles_per_wave > 0) load_tile(tA, 0);
-        for (int ti = 0; ti < tiles_per_wave; ti += 2) {
-            const bool has_b = ti + 1 < tiles_per_wave;
-            if (has_b) load_tile(tB, ti + 1);
-            process_tile(tA, ti);
-            if (has_b) {
-                if (ti + 2 < tiles_per_wave) load_tile(tA, ti + 2);
-                process_tile(tB, ti + 1);
-            }
-        }
-    }
-#else
     for (int ti = 0; ti < tiles_per_wave; ++ti) {   // two workgroups per CU hide the load latency instead
         TileIn tA;
         load_tile(tA, ti);
         process_tile(tA, ti);
     }
-#endif
 
     PRISM_STAMP(10);
     // ---- reduce the four waves in fixed order and write this workgroup's slab part -------------
