@@ -74,3 +74,10 @@ order = np.argsort(-d_)[:10]
 print("   longest post blocks (index: ticks):", ", ".join(f"{int(idx[i])}: {int(d_[i])}" for i in order))
 print("   post block duration by index decile:", [int(np.median(d_[(idx >= lo_) & (idx < hi_)])) if ((idx >= lo_) & (idx < hi_)).any() else 0
       for lo_, hi_ in zip(np.linspace(0, idx.max() + 1, 11)[:-1], np.linspace(0, idx.max() + 1, 11)[1:])])
+# tile_fwd per launch-order range (passes differ in cost: IQN publisher / consumer tiles, Q-head tiles)
+tb = s[:, [0, 7]].astype(np.float64)
+tb = tb[tb[:, 0] != 0]
+if len(tb) > 256:
+    d = tb[:, 1] - tb[:, 0]
+    q = len(d) // 8
+    print("tile_fwd block duration by launch-order octile:", [int(np.median(d[i * q:(i + 1) * q])) for i in range(8)], f"({len(d)} tiles)")
