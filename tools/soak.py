@@ -1,6 +1,6 @@
 """Soak run (GPU box): many fused hipGraph steps with periodic consistency checks -- the priority tree's
 parent = op(children) invariant on the device, finite parameters, self-resetting flags back at zero.
-Usage: python tools/soak.py [config index] [steps]"""
+Usage: python tools/soak.py [config index] [steps] [fill fraction: < 1 keeps the step on the eager (graph-free) path]"""
 import contextlib, io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +18,8 @@ with contextlib.redirect_stdout(io.StringIO()):
     ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
 ln.time_phases = False
 buf, ag = ln.experience_buffer, ln.agent
-fill_replay(buf, buf.capacity, seed=0)
+frac = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+fill_replay(buf, max(int(buf.capacity * frac), cfg.batch_size), seed=0)
 
 
 def check(tag):
