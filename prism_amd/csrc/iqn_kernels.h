@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) v[kt] = fold4(w + 4 * kt);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) dst[16 * kt] = v[kt];
+        for (int kt = 0; kt < 4; ++kt) __builtin_nontemporal_store(v[kt], dst + 16 * kt);
     }
     {
         // accW1[mt][r = w]: row h = 16*mt + 4*g + r, col n = cs*16 + j
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) v[mt] = fold4(16 + w + 4 * mt);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) dst[(int64_t)16 * mt * E_DIM] = v[mt];
+        for (int mt = 0; mt < 8; ++mt) __builtin_nontemporal_store(v[mt], dst + (int64_t)16 * mt * E_DIM);
     }
     if (w < 3 && g == 0) {
         const float v = fold4(48 + w);
