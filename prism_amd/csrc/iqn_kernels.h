@@ -666,8 +666,8 @@ __device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *l
         float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
         ga = pa[i] > 0.f ? ga : 0.f;
         gb = pb[i] > 0.f ? gb : 0.f;
-        a.ws.dpre1[r * H_DIM + lane] = ga;
-        a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
+        __builtin_nontemporal_store(ga, &a.ws.dpre1[r * H_DIM + lane]);
+        __builtin_nontemporal_store(gb, &a.ws.dpre1[r * H_DIM + 64 + lane]);
         const float c1 = wave_sum(ga * ua + gb * ub);
         const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
         if (lane == 0) {
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
         const float x = (rowf[m] * (float)(k + 1)) * PI_F;
         const float c = cosf(x);
         cost[m * CS + k] = c;
-        if (ps.save) a.ws.cosb[(int64_t)(r0 + m) * K_BASIS + k] = c;
+        if (ps.save) __builtin_nontemporal_store(c, &a.ws.cosb[(int64_t)(r0 + m) * K_BASIS + k]);   // read next by the backward launch
     }
     lds_barrier();
 
