@@ -50,6 +50,12 @@ constexpr int WAVE = 64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// 16-byte streaming store: data the NEXT launch consumes (it comes from HBM there anyway: kernel boundaries
+// write back and invalidate the L2s) goes out as the kernel runs instead of in the flush at its end
+__device__ __forceinline__ void stream_store4(float4 *dst, const float4 &v) {
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(dst));
+}
+
 // D = A(16x4) * B(4x16) + C, exact fp32 FMA chain.  Lane l supplies A[l&15][l>>4] and
 // B[l>>4][l&15]; D[row = 4*(l>>4) + r][col = l&15] lands in element r.
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

@@ -1042,17 +1042,17 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         // d e[b][n]: sum over the T rows of a sample
         float dcv = 0.f;          // ReLU-masked d e of (sample, column n) when it is final in this lane
         if (T == 4) {
-            a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+            if (!n_mine) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;       // (only the post-kernel conv role reads it)
         } else if (T == 8) {
             dep += __shfl_xor(dep, 16, 64);
-            if ((g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+            if (!n_mine && (g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
             dcv = ev > 0.f ? dep : 0.f;
         } else {
             dep += __shfl_xor(dep, 16, 64);
             dep += __shfl_xor(dep, 32, 64);
             de_acc += dep;
             if (((r0 + 16) % T) == 0) {
-                if (g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
+                if (!n_mine && g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
                 dcv = ev > 0.f ? de_acc : 0.f;
                 de_acc = 0.f;
             }

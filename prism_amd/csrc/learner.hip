@@ -95,9 +95,9 @@ __device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int 
         upd(g.y, p.y, m.y, v.y);
         upd(g.z, p.z, m.z, v.z);
         upd(g.w, p.w, m.w, v.w);
-        reinterpret_cast<float4 *>(a.p)[i] = p;
-        reinterpret_cast<float4 *>(a.m)[i] = m;
-        reinterpret_cast<float4 *>(a.v)[i] = v;
+        stream_store4(reinterpret_cast<float4 *>(a.p) + i, p);
+        stream_store4(reinterpret_cast<float4 *>(a.m) + i, m);
+        stream_store4(reinterpret_cast<float4 *>(a.v) + i, v);
     }
     if (blk == 0 && tid < (int)(a.n & 3)) {
         const int64_t i = (nvec << 2) + tid;

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                         if (c < a.n_chunks) {
                             s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
                         }
-                    *reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i) = s;
+                    stream_store4(reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i), s);
                     sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
                 }
                 done = true;
