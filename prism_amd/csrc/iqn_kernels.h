@@ -135,7 +135,7 @@ __device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, 
         const int q = (r >> 6) & 7, nt = (r >> 9) & 7, w = r >> 12;
         src = P + off.iqn_w1 + (int64_t)(16 * nt + li) * E_DIM + 128 * w + 16 * q + 4 * g;
     }
-    reinterpret_cast<float4 *>(pk)[p4] = *reinterpret_cast<const float4 *>(src);
+    reinterpret_cast<float4 *>(pk)[p4] = *reinterpret_cast<const float4 *>(src);   // (plain store: every CU of the next launch streams these)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -192,7 +192,7 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dst[(c0 + 4 * k) * 64 + (tid & 63)] = fmaxf(acc[k], 0.f);
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(fmaxf(acc[k], 0.f), &dst[(c0 + 4 * k) * 64 + (tid & 63)]);
     (void)nthreads;     // (256 threads: E_DIM / 4 positions-by-group)
 }
 

@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     for (int k = tid; k < O / 4; k += 256) {
         const float4 x = reinterpret_cast<const float4 *>(src_obs)[k];
         const float4 y = reinterpret_cast<const float4 *>(src_next)[k];
-        reinterpret_cast<float4 *>(d0)[k] = x;
-        reinterpret_cast<float4 *>(d1)[k] = y;
+        stream_store4(reinterpret_cast<float4 *>(d0) + k, x);
+        stream_store4(reinterpret_cast<float4 *>(d1) + k, y);
         reinterpret_cast<float4 *>(s_obs[0])[k] = x;
         reinterpret_cast<float4 *>(s_obs[1])[k] = y;
     }
