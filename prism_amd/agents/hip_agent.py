@@ -97,12 +97,17 @@ def _offsets(model):
     o.conv_w, o.conv_b = g("embedding_model.model.0.weight", -1), g("embedding_model.model.0.bias", -1)
     d = "distribution_model."
     o.phi_w, o.phi_b = g(d + "phi.0.weight", -1), g(d + "phi.0.bias", -1)
-    o.iqn_ln1_g, o.iqn_ln1_b = g(d + "model.model.0.weight", -1), g(d + "model.model.0.bias", -1)
-    o.iqn_w1, o.iqn_b1 = g(d + "model.model.1.weight", -1), g(d + "model.model.1.bias", -1)
-    o.iqn_ln2_g = g(d + "embedding_to_quantile_layer.0.weight", -1)
-    o.iqn_ln2_b = g(d + "embedding_to_quantile_layer.0.bias", -1)
-    o.iqn_w2 = g(d + "embedding_to_quantile_layer.1.weight", -1)
-    o.iqn_b2 = g(d + "embedding_to_quantile_layer.1.bias", -1)
+    if d + "model.model.1.weight" in table:          # LayerNorm on: [LN, Linear, ReLU] / [LN, Linear]
+        o.iqn_ln1_g, o.iqn_ln1_b = g(d + "model.model.0.weight", -1), g(d + "model.model.0.bias", -1)
+        o.iqn_w1, o.iqn_b1 = g(d + "model.model.1.weight", -1), g(d + "model.model.1.bias", -1)
+        o.iqn_ln2_g = g(d + "embedding_to_quantile_layer.0.weight", -1)
+        o.iqn_ln2_b = g(d + "embedding_to_quantile_layer.0.bias", -1)
+        o.iqn_w2 = g(d + "embedding_to_quantile_layer.1.weight", -1)
+        o.iqn_b2 = g(d + "embedding_to_quantile_layer.1.bias", -1)
+    else:                                            # use_layer_norm=False: [Linear, ReLU] / Linear (iqn_model.py:42-46)
+        o.iqn_w1, o.iqn_b1 = g(d + "model.model.0.weight", -1), g(d + "model.model.0.bias", -1)
+        o.iqn_w2 = g(d + "embedding_to_quantile_layer.weight", -1)
+        o.iqn_b2 = g(d + "embedding_to_quantile_layer.bias", -1)
     heads = sorted({int(k.split(".")[2]) for k in table if k.startswith("q_function_model.q_heads.")})
     if heads:
         pre = "q_function_model.q_heads.0."

@@ -1,0 +1,583 @@
+// Forward tiles of the TD update for gfx950: one 16-row tile per 512-thread workgroup, weights streamed
+// ONCE from L2 straight into MFMA operand registers, activations never leave the chip.
+//
+// Restates /root/reference/prism/agents/models/iqn_model.py:48-93 (+ ffnn_model.py:61-76) and the head
+// stack of q_ensemble.py:25-48.  Three kinds of tile share the code:
+//   kind 0  IQN rows (sample, tau) of one pass          input = ReLU(phi(cos basis)) * e
+//   kind 1  Q-head rows: 16 samples of one ensemble head input = e
+//   kind 2  IQN "mixed" tile: for each of its samples the T current-state rows AND the T next-state rows
+//           (same online weights: no target network), so the whole loss of those samples -- argmax,
+//           n-step target, T x T quantile-Huber tile, dL/dq, head + LayerNorm backward -- finishes inside the
+//           workgroup (iqn_model.py:95-201): no second launch, no cross-workgroup hand-off.
+//
+// Shape of the computation (everything transposed so that the accumulator of one product IS the operand of
+// the next; MFMA 16x16x4 fp32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[i = 4(l>>4)+r][j = l&15]):
+//   Y^T[n][m]    = Wphi[n][:] . cos[m][:]          A = Wphi (streamed), B = cos basis (16 registers per lane)
+//   x[n][m]      = ReLU(Y^T + bphi[n]) * e[b(m)][n]   (the bias is the initial accumulator)
+//   pre^T[h][m] += W1g[h][n] * x[n][m]             A = W1 (streamed, LayerNorm scale folded in), B = x: the D
+//                                                  registers of the first product, used as they stand
+// Wave w owns embed columns [128w, 128w + 128): eight 16-column steps, each 16 phi MFMAs + 4 * H/16 trunk
+// MFMAs, with no barrier and no LDS traffic between them.  LayerNorm(1024) is applied AFTER the GEMM from
+// the row sums the phi epilogue accumulates on the side:
+//   LN(x) . W1^T = rstd * (x . (g*W1)^T - mean * u) + v,   u = W1 g, v = W1 beta   (front kernel roles)
+// which is what removes the row-wide synchronisation between the two products.  The eight K-slices are
+// folded through LDS in wave order (bitwise reproducible), then LayerNorm(H) + head run with one row per
+// 32-lane half-wave.
+#pragma once
+#include "iqn_kernels.h"
+
+namespace prism {
+
+constexpr int FW_WAVES = 8;
+constexpr int FW_NT = E_DIM / 16 / FW_WAVES;     // 16-column steps per wave
+constexpr int FW_ZS = 17;                        // row stride of the Z tile in LDS
+
+template <int H>
+__host__ __device__ constexpr int fw_lds_floats() {
+    // cos tile | tau + loss scalars | row-stat partials | K-slice partials (reused by the loss fold) | Z tile | head weight
+    return 16 * CS + 128 + 2 * FW_WAVES * 16 + FW_WAVES * 16 * (H + 4) + 16 * FW_ZS + 16 + 16 * H;
+}
+
+// sum over the 32-lane half a lane belongs to; every lane of the half receives the total (fixed order)
+__device__ __forceinline__ float half_sum(float v) {
+    v += dpp_move<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+    v += dpp_move<0x124, 0xF>(0.f, v);    // row_ror:4
+    v += dpp_move<0x128, 0xF>(0.f, v);    // row_ror:8  -> every lane of a 16-lane row holds the row total
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);      // {row0,row0,row2,row2} + {row1,row1,row3,row3}
+}
+
+__device__ __forceinline__ f32x4 ld4(const float __attribute__((address_space(1))) *p, bool aligned) {
+    if (aligned) return *reinterpret_cast<const f32x4 __attribute__((address_space(1))) *>(p);
+    return f32x4{p[0], p[1], p[2], p[3]};
+}
+
+struct FwRow {           // what a lane needs to know about tile row m
+    int b, t, nx;        // sample, quantile index, 1 = next-state row (kind 2)
+    int64_t save;        // row index in the per-row save arrays, -1: not saved
+};
+
+template <int H, bool LN>
+__global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
+    constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *cost = smem;                          // [16][CS] cos basis of the tile's rows
+    float *rowf = cost + 16 * CS;                // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
+    float *stat = rowf + 128;                    // [2][8 waves][16 rows] partial row sums / sums of squares
+    float *part = stat + 2 * FW_WAVES * 16;      // [8 waves][16 rows][HP] K-slice partials
+    float *zt = part + FW_WAVES * 16 * HP;       // [16][FW_ZS] quantile / Q estimates of the tile
+    float *w2s = zt + 16 * FW_ZS + 16;           // [A][H] head Linear weight; b2 in rowf[96, 112)
+
+    // The pass this tile belongs to.  A runtime index into the by-value kernel argument would make the compiler
+    // copy the whole argument into scratch (and turn every pointer in it into a flat pointer), so the pass
+    // descriptor is read from the kernel-argument segment itself (scalar loads from constant memory) and its
+    // pointers are declared global.
+    typedef const float __attribute__((address_space(1))) *gcf;
+    typedef float __attribute__((address_space(1))) *gf;
+    (void)a_by_value;
+    const auto *kargs = (const __attribute__((address_space(4))) IqnArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) IqnArgs &a = *kargs;      // every use below reads the argument segment
+    int tile = blockIdx.x, pi = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (pi == i && i + 1 < a.n_pass && tile >= a.pass[i].n_tiles) {
+            tile -= a.pass[i].n_tiles;
+            pi = i + 1;
+        }
+    }
+    const __attribute__((address_space(4))) IqnPass *pp = &kargs->pass[pi];
+    const gcf ps_params = (gcf)pp->params, ps_wpk = (gcf)pp->wpk, ps_uv = (gcf)pp->uv;
+    const gcf ps_e = (gcf)pp->e, ps_e2 = (gcf)pp->e2, ps_tau_in = (gcf)pp->tau_in, ps_tau_in2 = (gcf)pp->tau_in2;
+    const gf ps_z_out = (gf)pp->z_out, ps_z_out2 = (gf)pp->z_out2;
+    const int ps_T = pp->T, ps_save = pp->save, ps_stream_id = pp->stream_id, ps_kind = pp->kind;
+    const int B = a.B, A = a.A;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, g = lane >> 4;
+    const int kind = ps_kind;
+    const int T = ps_T, tsh = 31 - __clz(T);
+    const gcf P = ps_params;
+    PRISM_STAMP(0);
+
+    int hd = 0, b0 = 0;
+    if (kind == 1) {
+        const int tiles_per_head = B / 16;
+        hd = tile / tiles_per_head;
+        b0 = (tile - hd * tiles_per_head) * 16;
+    }
+    auto row_of = [&](int m) __attribute__((always_inline)) {
+        FwRow r;
+        r.nx = 0;
+        if (kind == 1) {
+            r.b = b0 + m;
+            r.t = 0;
+            r.save = ps_save ? (int64_t)hd * B + r.b : -1;
+        } else if (kind == 0) {
+            const int row = tile * 16 + m;
+            r.b = row >> tsh;
+            r.t = row & (T - 1);
+            r.save = ps_save ? (int64_t)row : -1;
+        } else {
+            const int s = m >> (tsh + 1), j = m & (2 * T - 1);
+            r.b = tile * (16 >> (tsh + 1)) + s;
+            r.nx = j >= T;
+            r.t = j & (T - 1);
+            r.save = r.nx ? -1 : (int64_t)r.b * T + r.t;
+        }
+        return r;
+    };
+    const FwRow myrow = row_of(li);              // the row this lane feeds into the B operands (m = li)
+    // selects between two descriptor pointers stay OUT of the lambdas below: inside one, a select of two
+    // captured values becomes a load from a computed address of the closure object, which then -- with every
+    // array it references -- has to live in scratch
+    const gcf e_base = (kind == 2 && myrow.nx) ? ps_e2 : ps_e;
+    const FwRow trow = row_of(tid & 15);         // tid < 16: the row whose quantile sample this thread draws
+    const gcf tau_src = (kind == 2 && trow.nx) ? ps_tau_in2 : ps_tau_in;
+    const int tau_sid = (kind == 2 && trow.nx) ? 1 : ps_stream_id;
+
+    // head Linear weight [A][H] and bias: the oldest requests of the kernel, so that waiting for them later
+    // waits for nothing else (clamped indices: unconditional loads)
+    float w2r[H / 32], b2r;
+    {
+        const gcf Ph = kind == 1 ? P + a.off.head_base + (int64_t)hd * a.off.head_stride : P;
+        const gcf W2 = Ph + (kind == 1 ? a.off.h_w2 : a.off.iqn_w2), B2 = Ph + (kind == 1 ? a.off.h_b2 : a.off.iqn_b2);
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i) w2r[i] = W2[min(tid + 512 * i, A * H - 1)];
+        b2r = B2[min(tid, A - 1)];
+    }
+
+    f32x4 accT[NHT];
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) accT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+
+    // ---------------------------------------------------------------------------------------------
+    // the streamed products.  PHI: IQN rows (phi product feeds the trunk product); !PHI: Q-head rows.
+    // Every weight register is refilled for the next 16-column step right after its last use, so each
+    // wave keeps one step of its stream (4 + H/16 KB) in flight at all times.
+    // ---------------------------------------------------------------------------------------------
+    auto stream = [&](auto phi_tag) __attribute__((always_inline)) {
+        constexpr bool PHI = decltype(phi_tag)::value;
+        constexpr int SL = PHI ? NHT + 4 : NHT, W0 = PHI ? 4 : 0;
+        typedef const f32x4 __attribute__((address_space(1))) *gcf4;      // (native vectors: a HIP float4 loaded through an
+                                                                          // address-space pointer is copied via memory)
+        const gcf4 wp = reinterpret_cast<gcf4>(ps_wpk) + (kind == 1 ? (size_t)hd * (H * E_DIM / 4) : (size_t)0) +
+                           (size_t)(w * FW_NT) * SL * 64 + lane;
+        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
+        const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
+        // first requests: everything the first column step needs, plus what the second one needs before
+        // a refill of the first one's registers could land
+        f32x4 wphi0[4], wphi[4], w1[NHT], e4[2], b4[2];
+        if (PHI) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wphi0[q] = wp[q * 64];
+            b4[0] = *reinterpret_cast<gcf4>(brow);
+            b4[1] = *reinterpret_cast<gcf4>(brow + 16);
+        }
+        e4[0] = *reinterpret_cast<gcf4>(erow);
+        e4[1] = *reinterpret_cast<gcf4>(erow + 16);
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) w1[ht] = wp[(W0 + ht) * 64];
+        if (PHI) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wphi[q] = wp[(SL + q) * 64];
+        }
+        // the head Linear of the row phase (requested first of all): parked in LDS, read after the fold
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i)
+            if (tid + 512 * i < A * H) w2s[tid + 512 * i] = w2r[i];
+        if (tid < A) rowf[96 + tid] = b2r;
+
+        f32x4 cosB[4];
+        if (PHI) {
+            // quantile samples of the 16 rows, then their cos basis (iqn_model.py:89-93) through LDS
+            if (tid < 16) {
+                const FwRow r = trow;
+                const int sid = tau_sid;
+                const gcf tin = tau_src;
+                float tau;
+                if (tin) {
+                    tau = tin[(int64_t)r.t * B + r.b];
+                } else {
+                    uint32_t rr[4];
+                    Philox ph(a.seed);
+                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * B + r.b), 0x54415530ull + (uint64_t)sid, rr);
+                    tau = u32_to_unit_float(rr[0]);
+                }
+                if (a.tau_out) a.tau_out[(int64_t)sid * a.maxT * B + (int64_t)r.t * B + r.b] = tau;
+                rowf[tid] = tau;
+            }
+            lds_barrier();
+            // c[m][k] = cos(tau * (k+1) * pi), two fp32 multiplies as torch does (iqn_model.py:90-92)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 512 * i, m = idx >> 6, k = idx & 63;
+                const float c = cosf((rowf[m] * (float)(k + 1)) * PI_F);
+                cost[m * CS + k] = c;
+                const FwRow r = row_of(m);
+                if (r.save >= 0) __builtin_nontemporal_store(c, &a.ws.cosb[r.save * K_BASIS + k]);   // the backward launch reads it
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cosB[q] = *reinterpret_cast<const f32x4 *>(&cost[li * CS + 16 * q + 4 * g]);
+        }
+        PRISM_STAMP(1);
+
+        float x[4], xn[4];
+        f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+#define FW_SEL(v, c) ((v)[c])
+        // phi epilogue of column step `nt_e` (or the head rows' input); rolls the e / bias registers forward
+        // component r of column step nt_e's input; after the last component the e registers roll forward
+        auto finish_x = [&](float (&dst)[4], int nt_e, int r) __attribute__((always_inline)) {
+            const float ev = e4[nt_e & 1][r];
+            dst[r] = PHI ? fmaxf(pacc[r], 0.f) * ev : ev;
+            if (LN) {
+                s1 += dst[r];
+                s2 = fmaf(dst[r], dst[r], s2);
+            }
+            if (r == 3 && nt_e + 2 < FW_NT) e4[nt_e & 1] = *reinterpret_cast<gcf4>(erow + 16 * (nt_e + 2));
+        };
+        if (PHI) {
+            pacc = b4[0];          // bias = initial accumulator
+            b4[0] = *reinterpret_cast<gcf4>(brow + 32);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pacc = mfma16(FW_SEL(wphi0[i >> 2], i & 3), FW_SEL(cosB[i >> 2], i & 3), pacc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) finish_x(x, 0, r);
+        // The instruction order below IS the schedule: every slot is fenced, because left alone the scheduler
+        // sinks each weight load to just before its first use (trading the whole prefetch for registers
+        // nobody needs) and strings the links of the phi chain together (40-cycle stalls).
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < FW_NT; ++nt) {
+            const bool more = nt + 1 < FW_NT;
+            if (PHI && more) {
+                pacc = b4[(nt + 1) & 1];
+                if (nt + 3 < FW_NT) b4[(nt + 1) & 1] = *reinterpret_cast<gcf4>(brow + 16 * (nt + 3));
+            }
+            // trunk MFMAs of this step; the phi chain of the NEXT step is threaded between them (one phi MFMA
+            // behind each trunk MFMA until it is done: consecutive links of the chain are then two issue
+            // slots apart, more than the 40-cycle accumulator latency)
+#pragma unroll
+            for (int hp = 0; hp < NHT / 2; ++hp) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // phi steps carried by this (hp, r) slot: two while H = 128 (16 slots carry 16 + 16), one for H = 256
+                    const int p0 = NHT == 8 ? (hp * 4 + r) * 2 : hp * 4 + r, p1 = NHT == 8 ? p0 + 1 : 16;
+                    accT[2 * hp] = mfma16(FW_SEL(w1[2 * hp], r), x[r], accT[2 * hp]);
+                    if (PHI && more && p0 < 16) {
+                        pacc = mfma16(FW_SEL(wphi[p0 >> 2], p0 & 3), FW_SEL(cosB[p0 >> 2], p0 & 3), pacc);
+                        if ((p0 & 3) == 3 && nt + 2 < FW_NT) wphi[p0 >> 2] = wp[((nt + 2) * SL + (p0 >> 2)) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    accT[2 * hp + 1] = mfma16(FW_SEL(w1[2 * hp + 1], r), x[r], accT[2 * hp + 1]);
+                    if (PHI && more && p1 < 16) {
+                        pacc = mfma16(FW_SEL(wphi[p1 >> 2], p1 & 3), FW_SEL(cosB[p1 >> 2], p1 & 3), pacc);
+                        if ((p1 & 3) == 3 && nt + 2 < FW_NT) wphi[p1 >> 2] = wp[((nt + 2) * SL + (p1 >> 2)) * 64];
+                    }
+                    // the next step's input, one component per slot: a pair of trunk tiles after the phi chain
+                    // ended (its last MFMA has drained by then); head rows: in the last slots, when their e
+                    // registers have had a whole step to land
+                    if (more && hp == (PHI ? (NHT == 8 ? 2 : 4) : NHT / 2 - 1)) finish_x(xn, nt + 1, r);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {
+                    w1[2 * hp] = wp[((nt + 1) * SL + W0 + 2 * hp) * 64];
+                    w1[2 * hp + 1] = wp[((nt + 1) * SL + W0 + 2 * hp + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = xn[r];
+            }
+        }
+#undef FW_SEL
+    };
+    if (kind == 1) stream(std::false_type{});
+    else stream(std::true_type{});
+    PRISM_STAMP(2);
+
+    // ---- fold the eight K-slices ------------------------------------------------------------------
+    const int fm = tid >> 5, fc = tid & 31;          // fold / row phase: row fm, hidden units 4 fc .. 4 fc + 3 (+128)
+    const FwRow frow = row_of(fm);
+    // operands of the row phase: requested now, consumed after the barrier
+    const gcf Ptr = kind == 1 ? P + a.off.head_base + (int64_t)hd * a.off.head_stride : P;
+    const int64_t o_b1 = kind == 1 ? a.off.h_b1 : a.off.iqn_b1, o_g2 = kind == 1 ? a.off.h_ln2_g : a.off.iqn_ln2_g;
+    const int64_t o_be2 = kind == 1 ? a.off.h_ln2_b : a.off.iqn_ln2_b;
+    const bool al = kind != 1;                       // head tensors are only 4-byte aligned
+    const gcf uvp = ps_uv + (kind == 1 ? (size_t)hd * 2 * H : (size_t)0);
+    f32x4 u4[KPT], vb4[KPT], g24[KPT], be24[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int h0 = 128 * k + 4 * fc;
+        const f32x4 bb = ld4(Ptr + o_b1 + h0, al);
+        if (LN) {
+            u4[k] = ld4(uvp + h0, true);
+            vb4[k] = ld4(uvp + H + h0, true) + bb;
+            g24[k] = ld4(Ptr + o_g2 + h0, al);
+            be24[k] = ld4(Ptr + o_be2 + h0, al);
+        } else {
+            vb4[k] = bb;
+        }
+    }
+    if (LN) {
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) {
+            stat[w * 16 + li] = s1;
+            stat[(FW_WAVES + w) * 16 + li] = s2;
+        }
+    }
+#pragma unroll
+    for (int ht = 0; ht < NHT; ++ht)      // accT[ht][r] = pre^T[h = 16 ht + 4 g + r][m = li]
+        *reinterpret_cast<float4 *>(&part[(w * 16 + li) * HP + 16 * ht + 4 * g]) = float4{accT[ht][0], accT[ht][1], accT[ht][2], accT[ht][3]};
+    lds_barrier();
+    PRISM_STAMP(3);
+
+    float mean1 = 0.f, rstd1 = 1.f;
+    if (LN) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FW_WAVES; ++ww) {
+            t1 += stat[ww * 16 + fm];
+            t2 += stat[(FW_WAVES + ww) * 16 + fm];
+        }
+        mean1 = t1 * (1.0f / E_DIM);
+        const float var = fmaxf(t2 * (1.0f / E_DIM) - mean1 * mean1, 0.f);
+        rstd1 = 1.0f / sqrtf(var + LN_EPS);
+        if (frow.save >= 0 && fc == 0) {
+            (kind == 1 ? a.ws.q_mu1 : a.ws.mu1)[frow.save] = mean1;
+            (kind == 1 ? a.ws.q_rstd1 : a.ws.rstd1)[frow.save] = rstd1;
+        }
+    }
+    float pre[4 * KPT], hx[4 * KPT];           // pre-activation / what feeds the head Linear (xhat2 with LN, ReLU(pre) without)
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int h0 = 128 * k + 4 * fc;
+        float4 s = *reinterpret_cast<const float4 *>(&part[fm * HP + h0]);
+#pragma unroll
+        for (int ww = 1; ww < FW_WAVES; ++ww) {
+            const float4 p = *reinterpret_cast<const float4 *>(&part[(ww * 16 + fm) * HP + h0]);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            pre[4 * k + c] = LN ? rstd1 * (sv[c] - mean1 * u4[k][c]) + vb4[k][c] : sv[c] + vb4[k][c];
+    }
+    // ---- ReLU -> [LayerNorm(H)] -> head --------------------------------------------------------------
+    float rstd2 = 1.f;
+    {
+        float hs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * KPT; ++i) {
+            hx[i] = fmaxf(pre[i], 0.f);
+            hs += hx[i];
+        }
+        if (LN) {
+            const float mean2 = half_sum(hs) * (1.0f / H);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4 * KPT; ++i) {
+                hx[i] -= mean2;
+                vs = fmaf(hx[i], hx[i], vs);
+            }
+            rstd2 = 1.0f / sqrtf(half_sum(vs) * (1.0f / H) + LN_EPS);
+#pragma unroll
+            for (int i = 0; i < 4 * KPT; ++i) hx[i] *= rstd2;
+        }
+    }
+    const bool local_loss = kind == 2;
+    if (frow.save >= 0 && !local_loss) {
+        // saved for the loss / backward launches: pre-activation and the head Linear's input
+        float *sp = (kind == 1 ? a.ws.q_pre1 : a.ws.pre1) + frow.save * H, *sx = (kind == 1 ? a.ws.q_xhat2 : a.ws.xhat2) + frow.save * H;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int h0 = 128 * k + 4 * fc;
+            stream_store4(reinterpret_cast<float4 *>(sp + h0), float4{pre[4 * k], pre[4 * k + 1], pre[4 * k + 2], pre[4 * k + 3]});
+            stream_store4(reinterpret_cast<float4 *>(sx + h0), float4{hx[4 * k], hx[4 * k + 1], hx[4 * k + 2], hx[4 * k + 3]});
+        }
+        if (LN && fc == 0) (kind == 1 ? a.ws.q_rstd2 : a.ws.rstd2)[frow.save] = rstd2;
+    }
+    {
+        float y[4 * KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[4 * k + c] = LN ? hx[4 * k + c] * g24[k][c] + be24[k][c] : hx[4 * k + c];
+        }
+        float zmine = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < 16; ++aa)
+            if (aa < A) {
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < KPT; ++k) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(&w2s[aa * H + 128 * k + 4 * fc]);
+                    d += (y[4 * k] * wv.x + y[4 * k + 1] * wv.y) + (y[4 * k + 2] * wv.z + y[4 * k + 3] * wv.w);
+                }
+                const float z = half_sum(d);
+                if (fc == aa) zmine = z;
+            }
+        if (fc < A) {
+            zmine += rowf[96 + fc];
+            zt[fm * FW_ZS + fc] = zmine;
+            // quantile / Q estimates of the row (also what the stand-alone loss kernels read)
+            const gf zo = (kind == 2 && frow.nx) ? ps_z_out2 : ps_z_out;
+            const int64_t zr = kind == 1 ? (int64_t)hd * B + frow.b : (int64_t)frow.b * T + frow.t;
+            zo[zr * A + fc] = zmine;
+        }
+    }
+    PRISM_STAMP(4);
+    if (!local_loss) return;
+
+    // =================================================================================================
+    // kind 2: the loss of the tile's samples (iqn_model.py:95-201), then head + LayerNorm backward of their
+    // current-state rows, straight from the registers that still hold pre / xhat2 of every row.
+    // =================================================================================================
+    float *s_y = rowf + 16, *s_q = rowf + 32, *s_dq = rowf + 48;
+    const int ns = 16 >> (tsh + 1);                   // samples in this tile
+    // operands that do not depend on the loss: requested before the barrier
+    const int act_f = (int)a.action[frow.b];
+    float w2a[4 * KPT], uu[4 * KPT], vbv[4 * KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const float4 wv = *reinterpret_cast<const float4 *>(&w2s[act_f * H + 128 * k + 4 * fc]);
+        const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            w2a[4 * k + c] = LN ? wq[c] * g24[k][c] : wq[c];
+            uu[4 * k + c] = LN ? u4[k][c] : 0.f;
+            vbv[4 * k + c] = vb4[k][c];
+        }
+    }
+    lds_barrier();
+    if (w < ns) {
+        // one wave per sample: a* = argmax_a mean_j Zon[j][a] (first maximum wins, iqn_model.py:129-133)
+        const int smp = w, rb = smp * 2 * T, b = tile * ns + smp;
+        const int act = (int)a.action[b];
+        const float R = a.reward[b];
+        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
+        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+        const float kap = a.huber_k;
+        float mean = 0.f;
+        if (lane < A) {
+            float sacc = 0.f;
+            for (int j = 0; j < T; ++j) sacc += zt[(rb + T + j) * FW_ZS + lane];
+            mean = sacc / (float)T;
+        }
+        int astar = 0;
+        float bestv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), 0));
+#pragma unroll
+        for (int aa = 1; aa < 16; ++aa) {
+            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), aa));
+            if (aa < A && m > bestv) {
+                bestv = m;
+                astar = aa;
+            }
+        }
+        float *y = s_y + smp * T, *q = s_q + smp * T;
+        if (lane < T) {
+            y[lane] = R + zt[(rb + T + lane) * FW_ZS + astar] * dg;      // separate mul and add (iqn_model.py:145)
+            q[lane] = zt[(rb + lane) * FW_ZS + act];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
+        float lsum = 0.f, gq = 0.f;
+        const int t_l = lane & (T - 1);
+        const float q_l = q[t_l], tau_l = rowf[rb + t_l];
+        for (int p = lane; p < T * T; p += 64) {
+            const int j = p >> tsh;
+            const float d = y[j] - q_l;
+            const float ad = fabsf(d);
+            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
+            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
+            lsum += (wgt * hub) / kap;
+            const float cl = fminf(fmaxf(d, -kap), kap);
+            gq += (wgt * cl) / kap;
+        }
+        lsum = wave_sum(lsum);
+        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
+        const float dl = (lsum / (float)T) * a.dist_w;
+        const float scale = -(wb / (float)B) * a.dist_w / (float)T;
+        if (lane < T) s_dq[rb + lane] = gq * scale;
+        if (lane == 0) {
+            a.out_dl[b] = dl;
+            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
+            a.ws.lossw[b] = dl * wb;
+        }
+    }
+    lds_barrier();
+    PRISM_STAMP(5);
+    // head + LayerNorm(H) backward of row fm (current-state rows only; the other rows contribute nothing)
+    float *sS = part, *sP = part + 16 * HP;          // [16 rows][HP]: dq * (head input), dpre1
+    {
+        const bool cur = !frow.nx;
+        const float dq = cur ? s_dq[fm] : 0.f;
+        float da[4 * KPT], ga[4 * KPT];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * KPT; ++i) {
+            da[i] = dq * w2a[i];
+            m1 += da[i];
+            m2 = fmaf(da[i], hx[i], m2);
+        }
+        if (LN) {
+            m1 = half_sum(m1) * (1.0f / H);
+            m2 = half_sum(m2) * (1.0f / H);
+        }
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4 * KPT; ++i) {
+            const float gv = LN ? rstd2 * (da[i] - m1 - hx[i] * m2) : da[i];
+            ga[i] = pre[i] > 0.f ? gv : 0.f;
+            c1 = fmaf(ga[i], uu[i], c1);
+            c2 = fmaf(ga[i], pre[i] - vbv[i], c2);
+        }
+        if (LN) {
+            c1 = half_sum(c1);
+            c2 = half_sum(c2);
+        }
+        if (cur) {
+            float *dp = a.ws.dpre1 + frow.save * H;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k)
+                stream_store4(reinterpret_cast<float4 *>(dp + 128 * k + 4 * fc),
+                              float4{ga[4 * k], ga[4 * k + 1], ga[4 * k + 2], ga[4 * k + 3]});
+            if (fc == 0) {
+                if (LN) {
+                    a.ws.c1[frow.save] = c1;
+                    a.ws.c2[frow.save] = c2;
+                }
+                a.ws.dq[frow.save] = dq;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int h0 = 128 * k + 4 * fc;
+            *reinterpret_cast<float4 *>(&sS[fm * HP + h0]) = float4{dq * hx[4 * k], dq * hx[4 * k + 1], dq * hx[4 * k + 2], dq * hx[4 * k + 3]};
+            *reinterpret_cast<float4 *>(&sP[fm * HP + h0]) = float4{ga[4 * k], ga[4 * k + 1], ga[4 * k + 2], ga[4 * k + 3]};
+        }
+    }
+    lds_barrier();
+    // per sample: S_b[h] = sum_t dq_t x_t[h], P_b[h] = sum_t dpre1_t[h], D_b = sum_t dq_t (rows in order)
+    for (int o = tid; o < ns * 2 * H; o += 512) {
+        const int smp = o / (2 * H), k = o - smp * 2 * H, which = k >= H, h = which ? k - H : k;
+        const float *src = (which ? sP : sS) + (smp * 2 * T) * HP + h;
+        float t = 0.f;
+        for (int tt = 0; tt < T; ++tt) t += src[tt * HP];
+        (which ? a.ws.Pb : a.ws.Sb)[(int64_t)(tile * ns + smp) * H + h] = t;
+    }
+    if (tid < ns) {
+        float t = 0.f;
+        for (int tt = 0; tt < T; ++tt) t += s_dq[tid * 2 * T + tt];
+        a.ws.Db[tile * ns + tid] = t;
+    }
+    PRISM_STAMP(6);
+}
+
+}  // namespace prism

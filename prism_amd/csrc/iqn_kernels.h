@@ -29,31 +29,32 @@ namespace prism {
 
 constexpr int E_DIM = 1024;   // 16 * 8 * 8 (minatar_cnn_model.py:14)
 constexpr int K_BASIS = 64;   // iqn_n_basis_elements
-constexpr int H_DIM = 128;    // iqn_quantile_model_feature_dim
-constexpr int YS = E_DIM + 4; // LDS row strides (floats), +4 breaks the 16-row bank alias
-constexpr int CS = K_BASIS + 4;
-constexpr int HS = H_DIM + 4;
+constexpr int MAX_H = 256;    // hidden widths covered: 128 (MINATAR_CONFIG) and 256 (ablation presets)
+constexpr int CS = K_BASIS + 4;   // LDS row stride (floats) of a cos tile, +4 breaks the 16-row bank alias
 constexpr float LN_EPS = 1e-5f;
 constexpr float PI_F = 3.14159274101257324f;  // fp32(np.pi), the scalar torch multiplies by
 
 struct IqnPass {
     const float *params;  // weight set for this pass (online or target flat buffer)
-    const float *wphi_pk; // fragment-packed copies of phi.weight / trunk weight of that set (pack_weights_block)
-    const float *w1_pk;
+    const float *wpk;     // stream-packed weights of that set (pack_weights_block / pack_head_w1_block)
+    const float *uv;      // u | v of that set: IQN [2][H]; Q heads [heads][2][H]
     const float *e;       // [B][E] embedded observations feeding this pass
+    const float *e2;      // kind 2: embedded NEXT observations (the tile's next-state rows)
     const float *tau_in;  // [T*B] tau-major, or NULL -> Philox
+    const float *tau_in2; // kind 2: next-state quantile samples
     float *z_out;         // [B*T][A] sample-major
+    float *z_out2;        // kind 2: next-state estimates
     int T;
-    int n_tiles;          // B*T/16
+    int n_tiles;
     int save;             // current-state pass: keep what backward needs
     int stream_id;        // 0 cur, 1 next-online, 2 next-target
-    int kind;             // 0: IQN quantile rows, 1: Q-head rows (w1_pk = packed W1 of all heads, head-major)
-    int loss_role;        // fused loss (IqnArgs::loss_in_fwd): 1 = publishes its quantile rows, 2 = owns the loss
+    int kind;             // 0: IQN quantile rows of one pass, 1: Q-head rows, 2: IQN current + next rows of whole samples
 };
 
 struct IqnWs {           // workspace pointers (device)
-    float *e_cur, *e_next, *uv;
-    float *wpk[2];       // [online, target] fragment-packed {phi_w (E*K) | w1 (H*E)}
+    float *e_cur, *e_next;
+    float *uv;           // [2 sets][2][Hi]: u = W1 g1, v = W1 beta1 of the online / target IQN trunk
+    float *wpk[2];       // [online, target] stream-packed {phi_w, w1 * ln1_g}
     float *cosb, *mu1, *rstd1, *pre1, *xhat2, *rstd2;
     float *zcur, *zon, *ztg;
     float *dq, *c1, *c2, *dpre1, *Sb, *Pb, *Db, *lossw;
@@ -61,38 +62,40 @@ struct IqnWs {           // workspace pointers (device)
     // Q heads (rows indexed head*B + sample)
     float *q_mu1, *q_rstd1, *q_pre1, *q_xhat2, *q_rstd2;
     float *zq_cur, *zq_on, *zq_tg;
-    float *q_dq, *q_c1, *q_c2, *q_dpre1, *q_Sb, *q_Pb, *q_Db, *q_lossw;
-    float *q_uv;         // [heads][2][H]
-    float *q_kappa;      // [heads] Theil gradient factors, [heads] = theil value
-    float *q_wpk[2];     // [online, target] packed W1 of every head
+    float *q_dq, *q_c1, *q_c2, *q_dpre1, *q_lossw;
+    float *q_uv;         // [2 sets][heads][2][Hq]
+    float *q_kappa;      // [heads][Q_NORM_PARTS] partial ||theta_h||^2
+    float *q_wpk[2];     // [online, target] packed W1 * ln1_g of every head
     float *de_q;         // [heads][B][E] embedding gradient of each Q head
-    float *q_slabs;      // [heads][Q_SLAB]
-    float *slabs;        // [n_chunks][SLAB]
-    float *convpart;     // [ceil(B/CONV_SPB)][CONV_ROW]
+    float *q_slabs;      // [heads][q_slab]
+    float *slabs;        // [n_chunks][slab]
+    float *convpart;     // conv-backward partial rows
     float *normpart;     // [NORM_SLOTS]
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
     float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
-    unsigned int *loss_flag;   // [B*T/16] publisher count per current-state tile (zero-initialised, self-resetting)
     unsigned int *ticket;   // [4] {adam, conv, -, sibling-record state}, zero-initialised by the caller, self-resetting
 };
 
-constexpr int SLAB = E_DIM * K_BASIS + E_DIM + E_DIM + E_DIM + H_DIM * E_DIM;  // phi_w|phi_b|ln1_g|ln1_b|w1
-constexpr int NORM_SLOTS = 1280;
+constexpr int NORM_SLOTS = 2560;
+// gradient slab of one row chunk, in flat-parameter order: phi_w | phi_b | [ln1_g | ln1_b] | w1
+__host__ __device__ inline int iqn_slab_floats(int H, int ln) { return E_DIM * K_BASIS + E_DIM + (ln ? 2 * E_DIM : 0) + H * E_DIM; }
 
 struct IqnArgs {
     IqnPass pass[6];
     int n_pass;
     int B, A, C, T, Tn;
+    int Hi, Hq;            // hidden width of the IQN trunk / of the Q heads
+    int ln;                // use_layer_norm
+    int slab, q_slab;      // floats per gradient slab
     int n_chunks;          // row chunks of the backward
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
     int conv_in_bwd;       // conv-backward partials are produced by the tail of iqn_bwd_kernel (bwd_conv_ok)
-    int loss_in_fwd;       // > 0: the current-state tiles of tile_fwd run the loss of their samples once this many
-                           // next-state passes have published their rows (no separate iqn_loss_kernel launch)
-    int head_layers;       // 2: LN-Linear-ReLU-LN-Linear heads (MFMA path); 1: single Linear DQN head
+    int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
+    int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
-    unsigned long long *stamps;   // diagnostic builds only: [block][16] shader-clock stamps (dbg & 8)
+    unsigned long long *stamps;   // diagnostic builds only: [block][64] shader-clock stamps (dbg & 8)
     float huber_k, dist_w;
     prism_param_offsets off;
     const float *params;
@@ -110,32 +113,39 @@ struct IqnArgs {
 };
 
 // ------------------------------------------------------------------------------------------
-// Fragment-packed weight copies.  Reading the canonical [n][k] matrices in MFMA B-operand shape
-// touches 16 rows 4 KB apart per wave instruction and streams at ~16 B/clk/CU; the same bytes laid
-// out so that every wave instruction of tile_fwd reads 1 KB contiguous stream at 31-51 B/clk/CU
-// (tools/ubench/l2_stream.hip).  The copies are rebuilt from the canonical parameters by extra
-// blocks of the embed/front launch every step (0.8 MB, off the critical path), so they can never go
-// stale.  Layouts (float4 index):
-//   phi : [(wave w = n>>7) * 8 + (nt = (n>>4)&7)] * 4 + q   ][lane = g*16 + li]  = Wphi[n = 128w+16nt+li][16q+4g .. +3]
-//   w1  : [(wave w = k>>7) * 8 + (nt = h>>4)    ] * 8 + q   ][lane = g*16 + li]  = W1[h = 16nt+li][128w+16q+4g .. +3]
+// Stream-packed weight copies.  A forward tile consumes its weights as MFMA A operands, one 16-column
+// step of the embedding at a time; the copy lays them out in exactly that order, so each wave of a tile
+// reads ONE linear stream, 1 KB per wave instruction (reading the canonical [n][k] matrices in operand
+// shape touches 16 rows 4 KB apart per instruction and streams at half the rate: tools/ubench/l2_stream.hip).
+// LayerNorm(1024)'s scale is folded into the trunk weight here (fwd_kernels.h).  The copies are rebuilt
+// from the canonical parameters by extra blocks of the embed/front launch every step (off the critical
+// path), so they can never go stale.  float4 index of the IQN copy, SL = 4 + H/16 slots per step:
+//   [(step = n >> 4) * SL + slot][lane = g*16 + li]
+//     slot q < 4      : Wphi[n = 16 step + li][16 q + 4 g .. +3]
+//     slot 4 + ht     : W1[h = 16 ht + li][n = 16 step + 4 g .. +3] * g1[n]
+// (wave w of a tile owns steps 8w .. 8w+7).  A Q head's copy is the same without the phi slots.
 // ------------------------------------------------------------------------------------------
-constexpr int PACK_FLOATS = E_DIM * K_BASIS + H_DIM * E_DIM;
-constexpr int PACK_BLOCKS = PACK_FLOATS / 4 / 256;     // one float4 per thread, 256 threads: 192 blocks
+__host__ __device__ inline int iqn_pack_floats(int H) { return E_DIM * K_BASIS + H * E_DIM; }
+__host__ __device__ inline int iqn_pack_blocks(int H) { return iqn_pack_floats(H) / 4 / 256; }   // one float4 per thread
 
-__device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, const prism_param_offsets &off,
+__device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, const prism_param_offsets &off, int H, int ln,
                                                    float *__restrict__ pk, int blk, int tid) {
     const int p4 = blk * 256 + tid;              // packed float4 index
     const int lane = p4 & 63, li = lane & 15, g = lane >> 4;
-    const float *src;
-    if (p4 < E_DIM * K_BASIS / 4) {
-        const int q = (p4 >> 6) & 3, nt = (p4 >> 8) & 7, w = p4 >> 11;
-        src = P + off.phi_w + (int64_t)(128 * w + 16 * nt + li) * K_BASIS + 16 * q + 4 * g;
+    const int SL = 4 + H / 16;
+    const int grp = p4 >> 6, step = grp / SL, slot = grp - step * SL;
+    float4 v;
+    if (slot < 4) {
+        v = *reinterpret_cast<const float4 *>(P + off.phi_w + (int64_t)(16 * step + li) * K_BASIS + 16 * slot + 4 * g);
     } else {
-        const int r = p4 - E_DIM * K_BASIS / 4;
-        const int q = (r >> 6) & 7, nt = (r >> 9) & 7, w = r >> 12;
-        src = P + off.iqn_w1 + (int64_t)(16 * nt + li) * E_DIM + 128 * w + 16 * q + 4 * g;
+        const int n0 = 16 * step + 4 * g;
+        v = *reinterpret_cast<const float4 *>(P + off.iqn_w1 + (int64_t)(16 * (slot - 4) + li) * E_DIM + n0);
+        if (ln) {
+            const float4 gg = *reinterpret_cast<const float4 *>(P + off.iqn_ln1_g + n0);
+            v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
+        }
     }
-    reinterpret_cast<float4 *>(pk)[p4] = *reinterpret_cast<const float4 *>(src);   // (plain store: every CU of the next launch streams these)
+    reinterpret_cast<float4 *>(pk)[p4] = v;   // (plain store: every CU of the next launch streams these)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -143,9 +153,10 @@ __device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, 
 //        blocks [2B, 2B + H/4) compute u,v.
 // ------------------------------------------------------------------------------------------
 // u[h] = sum_n W1[h][n] g1[n],  v[h] = sum_n W1[h][n] beta1[n]   (one wave per h)
-__device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int h, int lane) {
-    const float *W1 = a.params + a.off.iqn_w1 + (int64_t)h * E_DIM;
-    const float *g1 = a.params + a.off.iqn_ln1_g, *b1 = a.params + a.off.iqn_ln1_b;
+__device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int set, int h, int lane) {
+    const float *P = set ? a.target_params : a.params;
+    const float *W1 = P + a.off.iqn_w1 + (int64_t)h * E_DIM;
+    const float *g1 = P + a.off.iqn_ln1_g, *b1 = P + a.off.iqn_ln1_b;
     float su = 0.f, sv = 0.f;
 #pragma unroll
     for (int n = lane * 4; n < E_DIM; n += 256) {
@@ -158,8 +169,8 @@ __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int h, int lane) 
     su = wave_sum(su);
     sv = wave_sum(sv);
     if (lane == 0) {
-        a.ws.uv[h] = su;
-        a.ws.uv[H_DIM + h] = sv;
+        a.ws.uv[(set * 2 + 0) * a.Hi + h] = su;
+        a.ws.uv[(set * 2 + 1) * a.Hi + h] = sv;
     }
 }
 
@@ -231,223 +242,64 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// tile_fwd: 512 threads = 8 waves, one 16-row tile per workgroup.  Two kinds of tile share the tail
-// [LayerNorm(1024) -> trunk GEMM (K = 1024) -> ReLU -> LayerNorm(128) -> head]:
-//   kind 0 (IQN, iqn_model.py:48-93)      rows = (sample, tau); input = ReLU(phi(cos basis)) * e
-//   kind 1 (Q head, q_ensemble.py:25-48)  rows = samples of one ensemble head; input = e
-// ------------------------------------------------------------------------------------------
-constexpr int PS = H_DIM + 4;   // row stride of the per-wave trunk partials
-constexpr int TILE_FWD_LDS_FLOATS = 16 * YS + 16 * CS + 16 * HS + 64 + 8 * 16 * PS;
-
-struct TrunkParams {      // one LN -> Linear -> ReLU -> LN -> Linear stack
-    const float *ln1_g, *ln1_b, *b1, *ln2_g, *ln2_b, *w2, *b2;
-    const float4 *w1pk;   // fragment-packed W1 of this stack
-};
-struct TileSave {         // what the backward of this tile needs (NULL pointers: nothing saved)
-    float *mu1, *rstd1, *pre1, *xhat2, *rstd2;
-    int64_t row0;         // index of the tile's first row in those arrays
-};
-
-// Tail shared by both kinds.  On entry: ytile holds the 16 x 1024 input rows (all waves' writes
-// issued, not yet synchronised), bt[0..3] hold this wave's K slice of output tiles 0..3.
-__device__ __forceinline__ void tile_trunk_head(const IqnArgs &a, const TrunkParams &tp, const TileSave &sv,
-                                                float *ytile, float *h1, float *part, float4 (&bt)[4][8],
-                                                float *z_out, int A) {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int li = lane & 15, g = lane >> 4;
-    const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
-    float4 lng[4], lnb[4];      // LayerNorm(1024) affine for this lane's 16 columns: in flight across the barrier
-    if (((reinterpret_cast<uintptr_t>(tp.ln1_g) | reinterpret_cast<uintptr_t>(tp.ln1_b)) & 15) == 0) {
-        // (IQN trunk: 16-byte aligned -- a quarter of the address traffic of the scalar form, which
-        // competes with the weight stream for the same address path)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lng[i] = reinterpret_cast<const float4 *>(tp.ln1_g)[i * 64 + lane];
-            lnb[i] = reinterpret_cast<const float4 *>(tp.ln1_b)[i * 64 + lane];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *pg = tp.ln1_g + (i * 64 + lane) * 4, *pb = tp.ln1_b + (i * 64 + lane) * 4;
-            lng[i] = float4{pg[0], pg[1], pg[2], pg[3]};     // head tensors are only 4-byte aligned
-            lnb[i] = float4{pb[0], pb[1], pb[2], pb[3]};
-        }
-    }
-    lds_barrier();
-
-    PRISM_STAMP(3);
-    // ---- LayerNorm(1024): wave w owns rows 2w, 2w+1; normalise in place ------------------------
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int m = 2 * w + rr;
-        float4 x[4];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[i] = *reinterpret_cast<const float4 *>(&ytile[m * YS + (i * 64 + lane) * 4]);
-            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-        }
-        const float mean = wave_sum(s) * (1.0f / E_DIM);
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
-            v += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
-        }
-        const float var = wave_sum(v) * (1.0f / E_DIM);
-        const float rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = (i * 64 + lane) * 4;
-            const float4 gg = lng[i], bb = lnb[i];
-            float4 y;
-            y.x = x[i].x * rstd * gg.x + bb.x;
-            y.y = x[i].y * rstd * gg.y + bb.y;
-            y.z = x[i].z * rstd * gg.z + bb.z;
-            y.w = x[i].w * rstd * gg.w + bb.w;
-            *reinterpret_cast<float4 *>(&ytile[m * YS + n]) = y;
-        }
-        if (sv.mu1 && lane == 0) {
-            sv.mu1[sv.row0 + m] = mean;
-            sv.rstd1[sv.row0 + m] = rstd;
-        }
-    }
-    lds_barrier();
-
-    PRISM_STAMP(4);
-    // ---- trunk GEMM (16 x 128, K = 1024), K split over the 8 waves ------------------------------
-    {
-        float4 at[8];   // A fragments of this wave's K slice, reused by all 8 output tiles
-#pragma unroll
-        for (int q = 0; q < 8; ++q) at[q] = *reinterpret_cast<const float4 *>(&ytile[li * YS + 128 * w + 16 * q + 4 * g]);
-        float *mypart = part + w * 16 * PS;
-#pragma unroll
-        for (int np = 0; np < 4; ++np) {        // output tiles 2np, 2np+1: ring slots (2np)&3, (2np+1)&3
-            const int s0 = (2 * np) & 3, s1 = (2 * np + 1) & 3;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                acc0 = mfma16(at[q].x, bt[s0][q].x, acc0);
-                acc1 = mfma16(at[q].x, bt[s1][q].x, acc1);
-                acc0 = mfma16(at[q].y, bt[s0][q].y, acc0);
-                acc1 = mfma16(at[q].y, bt[s1][q].y, acc1);
-                acc0 = mfma16(at[q].z, bt[s0][q].z, acc0);
-                acc1 = mfma16(at[q].z, bt[s1][q].z, acc1);
-                acc0 = mfma16(at[q].w, bt[s0][q].w, acc0);
-                acc1 = mfma16(at[q].w, bt[s1][q].w, acc1);
-            }
-            if (np < 2) {                        // refill the two slots just consumed with tiles +4
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    bt[s0][q] = W1pk[((2 * np + 4) * 8 + q) * 64];
-                    bt[s1][q] = W1pk[((2 * np + 5) * 8 + q) * 64];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mypart[(4 * g + r) * PS + 32 * np + li] = acc0[r];
-                mypart[(4 * g + r) * PS + 32 * np + 16 + li] = acc1[r];
-            }
-        }
-    }
-    // head operands: issue now, consume after two more barriers
-    const float g2a = tp.ln2_g[lane], g2b = tp.ln2_g[lane + 64], b2a = tp.ln2_b[lane], b2b = tp.ln2_b[lane + 64];
-    float w2a[16], w2b[16], b2r[16];
-#pragma unroll
-    for (int aa = 0; aa < 16; ++aa)
-        if (aa < A) {
-            w2a[aa] = tp.w2[aa * H_DIM + lane];
-            w2b[aa] = tp.w2[aa * H_DIM + 64 + lane];
-            b2r[aa] = tp.b2[aa];
-        }
-    const float b1v0 = tp.b1[tid & 127];
-    lds_barrier();
-    PRISM_STAMP(5);
-    // fold the 8 K-slices in fixed order, + bias, ReLU
-    for (int idx = tid; idx < 16 * H_DIM; idx += 512) {
-        const int m = idx >> 7, h = idx & 127;
-        float s = part[m * PS + h];
-#pragma unroll
-        for (int ww = 1; ww < 8; ++ww) s += part[(ww * 16 + m) * PS + h];
-        const float pre = s + b1v0;             // h == tid & 127 for every idx of this thread
-        h1[m * HS + h] = fmaxf(pre, 0.f);
-        if (sv.pre1) sv.pre1[(sv.row0 + m) * H_DIM + h] = pre;
-    }
-    lds_barrier();
-
-    PRISM_STAMP(6);
-    // ---- LayerNorm(128) + head (128 -> A): wave w owns rows 2w, 2w+1 ---------------------------
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int m = 2 * w + rr;
-        float x0 = h1[m * HS + lane], x1 = h1[m * HS + 64 + lane];
-        const float mean = wave_sum(x0 + x1) * (1.0f / H_DIM);
-        x0 -= mean;
-        x1 -= mean;
-        const float var = wave_sum(x0 * x0 + x1 * x1) * (1.0f / H_DIM);
-        const float rstd = 1.0f / sqrtf(var + LN_EPS);
-        const float xh0 = x0 * rstd, xh1 = x1 * rstd;
-        const float y0 = xh0 * g2a + b2a, y1 = xh1 * g2b + b2b;
-        if (sv.xhat2) {
-            sv.xhat2[(sv.row0 + m) * H_DIM + lane] = xh0;
-            sv.xhat2[(sv.row0 + m) * H_DIM + 64 + lane] = xh1;
-            if (lane == 0) sv.rstd2[sv.row0 + m] = rstd;
-        }
-#pragma unroll
-        for (int aa = 0; aa < 16; ++aa)
-            if (aa < A) {
-                const float z = wave_sum(y0 * w2a[aa] + y1 * w2b[aa]) + b2r[aa];
-                // write-through: a workgroup of this same launch may consume the row (fused loss)
-                if (lane == 0) __hip_atomic_store(&z_out[(int64_t)m * A + aa], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-    }
-    PRISM_STAMP(7);
-}
-
 constexpr int LOSS_WAVES = 8;
 constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
 
-// One sample's quantile-Huber loss + head/LayerNorm(128) backward, by a 512-thread workgroup.
-// `lds`: LOSS_LDS_FLOATS floats.  `coherent_next`: the next-state quantile rows were written by other
-// workgroups of the SAME launch (fused tail of tile_fwd) -> read them with agent-scope loads.
-constexpr int LOSS_LDS_FLOATS = 3 * 64 * 16 + 4 * 64 + LOSS_WAVES * (4 * 64 + 4) + 4;
-__device__ __forceinline__ void iqn_loss_sample(const IqnArgs &a, int b, float *lds, bool coherent_next) {
+// ------------------------------------------------------------------------------------------
+// loss (stand-alone form, iqn_model.py:95-201): one workgroup (8 waves) per sample, for the shapes whose
+// loss cannot finish inside a forward tile (target network, T > 8, T' != T).  Wave 0 evaluates the
+// pairwise quantile-Huber tile while every wave already has the saved activations of its rows in
+// flight; then the T current-state rows are back-propagated through head + LayerNorm(H), rows strided
+// over waves.  T, T' must divide 64.  `xhat2` holds the head Linear's input: LayerNorm output before the
+// affine (LN) or ReLU(pre1) (no LN).
+// ------------------------------------------------------------------------------------------
+template <int H>
+__host__ __device__ constexpr int loss_lds_floats() { return 3 * 64 * 16 + 4 * 64 + LOSS_WAVES * (2 * H + 4) + 4; }
+
+template <int H, bool LN>
+__global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
+    constexpr int KH = H / 64, AS = 2 * H + 4;
+    __shared__ __attribute__((aligned(16))) float lds[loss_lds_floats<H>()];
     float *s_zc = lds, *s_zo = s_zc + 64 * 16, *s_zt = s_zo + 64 * 16;
     float *s_y = s_zt + 64 * 16, *s_q = s_y + 64, *s_tau = s_q + 64, *s_dq = s_tau + 64;
-    float(*s_acc)[4 * 64 + 4] = reinterpret_cast<float(*)[4 * 64 + 4]>(s_dq + 64);
-    int &s_astar = *reinterpret_cast<int *>(s_dq + 64 + LOSS_WAVES * (4 * 64 + 4));
+    float *s_acc = s_dq + 64;                     // [LOSS_WAVES][AS]
+    int &s_astar = *reinterpret_cast<int *>(s_acc + LOSS_WAVES * AS);
+    const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
     const float kap = a.huber_k;
 
     // rows of this wave: t = w, w + 8, ...; start their loads now, they do not depend on the loss
-    float xa[LOSS_RPW], xb[LOSS_RPW], pa[LOSS_RPW], pb[LOSS_RPW], rs[LOSS_RPW];
+    float xa[LOSS_RPW][KH], pa[LOSS_RPW][KH], rs[LOSS_RPW];
 #pragma unroll
     for (int i = 0; i < LOSS_RPW; ++i) {
         const int t = w + LOSS_WAVES * i;
+        rs[i] = 1.f;
         if (t < T) {
             const int64_t r = (int64_t)b * T + t;
-            xa[i] = a.ws.xhat2[r * H_DIM + lane];
-            xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
-            pa[i] = a.ws.pre1[r * H_DIM + lane];
-            pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
-            rs[i] = a.ws.rstd2[r];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                xa[i][k] = a.ws.xhat2[r * H + 64 * k + lane];
+                pa[i][k] = a.ws.pre1[r * H + 64 * k + lane];
+            }
+            if (LN) rs[i] = a.ws.rstd2[r];
         }
     }
     const int act = (int)a.action[b];
     const float *P = a.params;
-    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
-    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
-    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
-    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
-    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
-
+    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H;
+    float w2a[KH], ua[KH], va[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        const int h = 64 * k + lane;
+        w2a[k] = LN ? W2[h] * P[a.off.iqn_ln2_g + h] : W2[h];          // d (head input) / dq
+        ua[k] = LN ? a.ws.uv[h] : 0.f;
+        va[k] = (LN ? a.ws.uv[H + h] : 0.f) + P[a.off.iqn_b1 + h];
+    }
     for (int i = tid; i < T * A; i += 64 * LOSS_WAVES) s_zc[i] = a.ws.zcur[(int64_t)b * T * A + i];
     for (int i = tid; i < Tn * A; i += 64 * LOSS_WAVES) {
-        const float *po = a.ws.zon + (int64_t)b * Tn * A + i, *pt = a.ws.ztg + (int64_t)b * Tn * A + i;
-        s_zo[i] = coherent_next ? __hip_atomic_load(po, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *po;
-        s_zt[i] = coherent_next ? __hip_atomic_load(pt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *pt;
+        s_zo[i] = a.ws.zon[(int64_t)b * Tn * A + i];
+        s_zt[i] = a.ws.ztg[(int64_t)b * Tn * A + i];
     }
     // quantile samples of the current-state pass (tau_out slot 0 always holds them)
     if (tid < T) s_tau[tid] = a.tau_out[(int64_t)tid * B + b];
@@ -505,365 +357,68 @@ __device__ __forceinline__ void iqn_loss_sample(const IqnArgs &a, int b, float *
     __syncthreads();
     PRISM_STAMP(22);
 
-    // head + LayerNorm(128) backward for this wave's rows
-    float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
+    // head + LayerNorm(H) backward for this wave's rows
+    float Sa[KH], Pa[KH], Dsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) Sa[k] = Pa[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < LOSS_RPW; ++i) {
         const int t = w + LOSS_WAVES * i;
         if (t < T) {
             const int64_t r = (int64_t)b * T + t;
             const float dq = s_dq[t];
-            const float da = dq * w2a, db = dq * w2b;
-            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
-            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
-            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
-            ga = pa[i] > 0.f ? ga : 0.f;
-            gb = pb[i] > 0.f ? gb : 0.f;
-            a.ws.dpre1[r * H_DIM + lane] = ga;
-            a.ws.dpre1[r * H_DIM + 64 + lane] = gb;
-            const float c1 = wave_sum(ga * ua + gb * ub);
-            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+            float da[KH], ga[KH], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                da[k] = dq * w2a[k];
+                m1 += da[k];
+                m2 += da[k] * xa[i][k];
+            }
+            if (LN) {
+                m1 = wave_sum(m1) * (1.0f / H);
+                m2 = wave_sum(m2) * (1.0f / H);
+            }
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const float gv = LN ? rs[i] * (da[k] - m1 - xa[i][k] * m2) : da[k];
+                ga[k] = pa[i][k] > 0.f ? gv : 0.f;
+                a.ws.dpre1[r * H + 64 * k + lane] = ga[k];
+                c1 += ga[k] * ua[k];
+                c2 += ga[k] * (pa[i][k] - va[k]);
+                Sa[k] += dq * xa[i][k];
+                Pa[k] += ga[k];
+            }
+            if (LN) {
+                c1 = wave_sum(c1);
+                c2 = wave_sum(c2);
+            }
             if (lane == 0) {
-                a.ws.c1[r] = c1;
-                a.ws.c2[r] = c2;
+                if (LN) {
+                    a.ws.c1[r] = c1;
+                    a.ws.c2[r] = c2;
+                }
                 a.ws.dq[r] = dq;
             }
-            Sa += dq * xa[i];
-            Sbb += dq * xb[i];
-            Pa += ga;
-            Pbb += gb;
             Dsum += dq;
         }
     }
-    s_acc[w][lane] = Sa;
-    s_acc[w][64 + lane] = Sbb;
-    s_acc[w][128 + lane] = Pa;
-    s_acc[w][192 + lane] = Pbb;
-    if (lane == 0) s_acc[w][256] = Dsum;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+        s_acc[w * AS + 64 * k + lane] = Sa[k];
+        s_acc[w * AS + H + 64 * k + lane] = Pa[k];
+    }
+    if (lane == 0) s_acc[w * AS + 2 * H] = Dsum;
     __syncthreads();
     PRISM_STAMP(23);
-    if (tid < 256) {
+    for (int o = tid; o < 2 * H + 1; o += 64 * LOSS_WAVES) {
         float t = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][tid];
-        if (tid < 128) a.ws.Sb[(int64_t)b * H_DIM + tid] = t;
-        else a.ws.Pb[(int64_t)b * H_DIM + (tid - 128)] = t;
-    } else if (tid == 256) {
-        float t = 0.f;
-        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww][256];
-        a.ws.Db[b] = t;
+        for (int ww = 0; ww < LOSS_WAVES; ++ww) t += s_acc[ww * AS + o];
+        if (o < H) a.ws.Sb[(int64_t)b * H + o] = t;
+        else if (o < 2 * H) a.ws.Pb[(int64_t)b * H + (o - H)] = t;
+        else a.ws.Db[b] = t;
     }
-}
-
-// The same computation for ALL samples of one 16-row current-state tile at once (fused tail of
-// tile_fwd; needs 16 % T == 0 and Tn == T, so the tile's samples own next-state rows r0..r0+15 too).
-// Wave w owns tile rows 2w and 2w+1; the first wave of a sample's group computes its argmax and
-// quantile-Huber block.  The next-state rows come from other workgroups of this launch: agent-scope loads.
-constexpr int LOSS_TILE_LDS_FLOATS = 3 * 256 + 4 * 16 + LOSS_WAVES * (4 * 64 + 4);
-// `flag` / `need`: the publisher count of this tile; waited for only after every operand that does not
-// depend on the publishers has been requested.
-__device__ __forceinline__ void iqn_loss_tile(const IqnArgs &a, int r0, float *lds, unsigned int *flag, unsigned int need) {
-    float *s_zc = lds, *s_zo = s_zc + 256, *s_zt = s_zo + 256;          // [16 rows][A <= 16]
-    float *s_y = s_zt + 256, *s_q = s_y + 16, *s_tau = s_q + 16, *s_dq = s_tau + 16;
-    float(*s_acc)[4 * 64 + 4] = reinterpret_cast<float(*)[4 * 64 + 4]>(s_dq + 16);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int B = a.B, A = a.A, T = a.T;
-    const float kap = a.huber_k;
-    const int wps = T / 2;                       // waves per sample (8 waves x 2 rows = 16 rows)
-    const int smp = (2 * w) / T;                 // local sample of this wave
-    const int b = r0 / T + smp;
-    float xa[2], xb[2], pa[2], pb[2], rs[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t r = (int64_t)r0 + 2 * w + i;
-        xa[i] = a.ws.xhat2[r * H_DIM + lane];
-        xb[i] = a.ws.xhat2[r * H_DIM + 64 + lane];
-        pa[i] = a.ws.pre1[r * H_DIM + lane];
-        pb[i] = a.ws.pre1[r * H_DIM + 64 + lane];
-        rs[i] = a.ws.rstd2[r];
-    }
-    const int act = (int)a.action[b];
-    const float *P = a.params;
-    const float *W2 = P + a.off.iqn_w2 + (int64_t)act * H_DIM;
-    const float *g2 = P + a.off.iqn_ln2_g, *b1 = P + a.off.iqn_b1;
-    const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];  // d xhat2 / dq
-    const float ua = a.ws.uv[lane], ub = a.ws.uv[lane + 64];
-    const float va = a.ws.uv[H_DIM + lane] + b1[lane], vb = a.ws.uv[H_DIM + lane + 64] + b1[lane + 64];
-    const float R = a.reward[b];
-    const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-    const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
-    if (tid < 16 * A) s_zc[tid] = a.ws.zcur[(int64_t)r0 * A + tid];
-    // quantile samples of the current-state pass (tau_out slot 0 always holds them)
-    if (tid < 16) s_tau[tid] = a.tau_out[(int64_t)(tid % T) * B + (r0 / T + tid / T)];
-    // everything above is this workgroup's own data; now the publishers' rows
-    if (tid == 0) {
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
-        __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (tid < 16 * A) {
-        s_zo[tid] = __hip_atomic_load(a.ws.zon + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_zt[tid] = __hip_atomic_load(a.ws.ztg + (int64_t)r0 * A + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (w % wps == 0) {
-        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133): lane = action
-        float mean = 0.f;
-        if (lane < A) {
-            float sacc = 0.f;
-            for (int j = 0; j < T; ++j) sacc += s_zo[(smp * T + j) * A + lane];
-            mean = sacc / (float)T;
-        }
-        int astar = 0;
-        float bestv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), 0));
-#pragma unroll
-        for (int aa = 1; aa < 16; ++aa) {
-            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), aa));
-            if (aa < A && m > bestv) {
-                bestv = m;
-                astar = aa;
-            }
-        }
-        float *y = s_y + smp * T, *q = s_q + smp * T;
-        if (lane < T) y[lane] = R + s_zt[(smp * T + lane) * A + astar] * dg;   // separate mul and add (iqn_model.py:145)
-        if (lane < T) q[lane] = s_zc[(smp * T + lane) * A + act];
-        __builtin_amdgcn_wave_barrier();
-        // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
-        float lsum = 0.f, gq = 0.f;
-        const int t_l = lane % T;
-        const float q_l = q[t_l], tau_l = s_tau[smp * T + t_l];
-        for (int p = lane; p < T * T; p += 64) {
-            const int j = p / T;
-            const float d = y[j] - q_l;
-            const float ad = fabsf(d);
-            const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
-            const float wgt = fabsf(tau_l - (d < 0.f ? 1.0f : 0.0f));
-            lsum += (wgt * hub) / kap;
-            const float cl = fminf(fmaxf(d, -kap), kap);
-            gq += (wgt * cl) / kap;
-        }
-        lsum = wave_sum(lsum);
-        for (int o = 32; o >= T; o >>= 1) gq += __shfl_xor(gq, o, 64);
-        const float dl = (lsum / (float)T) * a.dist_w;
-        const float scale = -(wb / (float)B) * a.dist_w / (float)T;
-        if (lane < T) s_dq[smp * T + lane] = gq * scale;
-        if (lane == 0) {
-            a.out_dl[b] = dl;
-            if (a.out_td && a.n_heads == 0) a.out_td[b] = dl;  // IQN only: td_errors = distribution_loss (composite_model.py:138-139)
-            a.ws.lossw[b] = dl * wb;
-        }
-    }
-    __syncthreads();
-    // head + LayerNorm(128) backward for this wave's two rows
-    float Sa = 0.f, Sbb = 0.f, Pa = 0.f, Pbb = 0.f, Dsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t r = (int64_t)r0 + 2 * w + i;
-        const float dq = s_dq[2 * w + i];
-        const float da = dq * w2a, db = dq * w2b;
-        const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
-        const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
-        float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
-        ga = pa[i] > 0.f ? ga : 0.f;
-        gb = pb[i] > 0.f ? gb : 0.f;
-        __builtin_nontemporal_store(ga, &a.ws.dpre1[r * H_DIM + lane]);
-        __builtin_nontemporal_store(gb, &a.ws.dpre1[r * H_DIM + 64 + lane]);
-        const float c1 = wave_sum(ga * ua + gb * ub);
-        const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
-        if (lane == 0) {
-            a.ws.c1[r] = c1;
-            a.ws.c2[r] = c2;
-            a.ws.dq[r] = dq;
-        }
-        Sa += dq * xa[i];
-        Sbb += dq * xb[i];
-        Pa += ga;
-        Pbb += gb;
-        Dsum += dq;
-    }
-    s_acc[w][lane] = Sa;
-    s_acc[w][64 + lane] = Sbb;
-    s_acc[w][128 + lane] = Pa;
-    s_acc[w][192 + lane] = Pbb;
-    if (lane == 0) s_acc[w][256] = Dsum;
-    __syncthreads();
-    // per sample: fold its group of waves in order
-    const int ns = 16 / T;
-    for (int o = tid; o < ns * 257; o += 64 * LOSS_WAVES) {
-        const int sm = o / 257, k = o - sm * 257;
-        float t = 0.f;
-        for (int ww = 0; ww < wps; ++ww) t += s_acc[sm * wps + ww][k];
-        const int bb = r0 / T + sm;
-        if (k < 128) a.ws.Sb[(int64_t)bb * H_DIM + k] = t;
-        else if (k < 256) a.ws.Pb[(int64_t)bb * H_DIM + (k - 128)] = t;
-        else a.ws.Db[bb] = t;
-    }
-}
-
-__global__ __launch_bounds__(512) void iqn_tile_fwd_kernel(IqnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *ytile = smem;
-    float *cost = ytile + 16 * YS;
-    float *h1 = cost + 16 * CS;
-    float *rowf = h1 + 16 * HS;                 // [0,16) tau
-    float *part = rowf + 64;                    // [8 waves][16 rows][PS] K-split partials of the trunk GEMM
-
-    int tile = blockIdx.x, pi = 0;
-    while (pi < a.n_pass - 1 && tile >= a.pass[pi].n_tiles) {
-        tile -= a.pass[pi].n_tiles;
-        ++pi;
-    }
-    const IqnPass ps = a.pass[pi];
-    const int B = a.B, A = a.A;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int li = lane & 15, g = lane >> 4;
-    const float *P = ps.params;
-    float4 bt[4][8];       // [ring slot][q]: trunk B operand, B[k = 128w + 16q + 4g + jj][h = 16nt + li]
-    PRISM_STAMP(0);
-
-    if (ps.kind == 1) {
-        // ---- Q-head tile: 16 samples of ensemble head hd; input rows are the embeddings -----------
-        const int tiles_per_head = B / 16;
-        const int hd = tile / tiles_per_head, b0 = (tile - hd * tiles_per_head) * 16;
-        const float *Ph = P + a.off.head_base + (int64_t)hd * a.off.head_stride;
-        TrunkParams tp{Ph + a.off.h_ln1_g, Ph + a.off.h_ln1_b, Ph + a.off.h_b1, Ph + a.off.h_ln2_g, Ph + a.off.h_ln2_b,
-                       Ph + a.off.h_w2, Ph + a.off.h_b2,
-                       reinterpret_cast<const float4 *>(ps.w1_pk + (size_t)hd * H_DIM * E_DIM)};
-        const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bt[nt][q] = W1pk[(nt * 8 + q) * 64];
-        // rows: 16 x 4 KB contiguous in e -> LDS (wave w copies rows 2w, 2w+1)
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int m = 2 * w + rr;
-            const float4 *src = reinterpret_cast<const float4 *>(ps.e + (int64_t)(b0 + m) * E_DIM);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4 *>(&ytile[m * YS + (i * 64 + lane) * 4]) = src[i * 64 + lane];
-        }
-        const int64_t row0 = (int64_t)hd * B + b0;
-        TileSave sv{ps.save ? a.ws.q_mu1 : nullptr, a.ws.q_rstd1, ps.save ? a.ws.q_pre1 : nullptr,
-                    ps.save ? a.ws.q_xhat2 : nullptr, a.ws.q_rstd2, row0};
-        PRISM_STAMP(1);
-        PRISM_STAMP(2);
-        tile_trunk_head(a, tp, sv, ytile, h1, part, bt, ps.z_out + row0 * A, A);
-        return;
-    }
-
-    const int T = ps.T;
-    const int r0 = tile * 16;
-    // Weights do not depend on anything computed here: put the whole phi B operand of this wave
-    // (8 column tiles x K = 64) in flight before the first barrier.
-    const float *bphi = P + a.off.phi_b;
-    float4 bq[8][4];       // [tile][q]: B[k = 16q + 4g + jj][n = 128w + 16nt + li], 1 KB contiguous per wave load
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(ps.wphi_pk) + (size_t)w * 8 * 4 * 64 + lane;
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[nt][q] = src[(nt * 4 + q) * 64];
-    }
-    // phi epilogue operands (bias, embedded observation of the row group's sample): also early
-    const float *erow = ps.e + (int64_t)((r0 + 4 * g) / T) * E_DIM;   // rows 4g..4g+3 share a sample (T % 4 == 0)
-    float pb_[8], pe_[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-        pb_[nt] = bphi[w * 128 + nt * 16 + li];
-        pe_[nt] = erow[w * 128 + nt * 16 + li];
-    }
-
-    if (tid < 16) {
-        const int r = r0 + tid, b = r / T, t = r - b * T;
-        float tau;
-        if (ps.tau_in) {
-            tau = ps.tau_in[(int64_t)t * B + b];
-        } else {
-            uint32_t rr[4];
-            Philox ph(a.seed);
-            ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)t * B + b), 0x54415530ull + (uint64_t)ps.stream_id, rr);
-            tau = u32_to_unit_float(rr[0]);
-        }
-        if (a.tau_out) a.tau_out[(int64_t)ps.stream_id * a.maxT * B + (int64_t)t * B + b] = tau;
-        rowf[tid] = tau;
-    }
-    lds_barrier();
-    // cos basis: c[m][k] = cos(tau * (k+1) * pi), two fp32 multiplies as torch does (iqn_model.py:90-92)
-    for (int idx = tid; idx < 16 * K_BASIS; idx += 512) {
-        const int m = idx >> 6, k = idx & 63;
-        const float x = (rowf[m] * (float)(k + 1)) * PI_F;
-        const float c = cosf(x);
-        cost[m * CS + k] = c;
-        if (ps.save) __builtin_nontemporal_store(c, &a.ws.cosb[(int64_t)(r0 + m) * K_BASIS + k]);   // read next by the backward launch
-    }
-    lds_barrier();
-
-    PRISM_STAMP(1);
-    TrunkParams tp{P + a.off.iqn_ln1_g, P + a.off.iqn_ln1_b, P + a.off.iqn_b1, P + a.off.iqn_ln2_g, P + a.off.iqn_ln2_b,
-                   P + a.off.iqn_w2,    P + a.off.iqn_b2,    reinterpret_cast<const float4 *>(ps.w1_pk)};
-    // Trunk weights: wave w owns the K slice [128w, 128w+128) for ALL 128 outputs.  The first four
-    // output tiles' B operand is requested tile by tile WHILE the phi tiles are being consumed, so the
-    // weight stream never pauses between the two GEMMs.
-    const float4 *W1pk = tp.w1pk + (size_t)w * 8 * 8 * 64 + lane;
-    // ---- phi GEMM (16 x 1024, K = 64) + bias + ReLU + Hadamard with e -> ytile ----------------
-    // two column tiles at a time: their MFMA chains interleave, so no chain waits on itself
-    {
-        float4 afr[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) afr[q] = *reinterpret_cast<const float4 *>(&cost[li * CS + 16 * q + 4 * g]);
-#pragma unroll
-        for (int np = 0; np < 4; ++np) {
-            const int n0 = w * 128 + np * 32 + li, n1 = n0 + 16;
-            const float bias0 = pb_[2 * np], ev0 = pe_[2 * np], bias1 = pb_[2 * np + 1], ev1 = pe_[2 * np + 1];
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc0 = mfma16(afr[q].x, bq[2 * np][q].x, acc0);
-                acc1 = mfma16(afr[q].x, bq[2 * np + 1][q].x, acc1);
-                acc0 = mfma16(afr[q].y, bq[2 * np][q].y, acc0);
-                acc1 = mfma16(afr[q].y, bq[2 * np + 1][q].y, acc1);
-                acc0 = mfma16(afr[q].z, bq[2 * np][q].z, acc0);
-                acc1 = mfma16(afr[q].z, bq[2 * np + 1][q].z, acc1);
-                acc0 = mfma16(afr[q].w, bq[2 * np][q].w, acc0);
-                acc1 = mfma16(afr[q].w, bq[2 * np + 1][q].w, acc1);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ytile[(4 * g + r) * YS + n0] = fmaxf(acc0[r] + bias0, 0.f) * ev0;
-                ytile[(4 * g + r) * YS + n1] = fmaxf(acc1[r] + bias1, 0.f) * ev1;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bt[np][q] = W1pk[(np * 8 + q) * 64];   // one trunk tile per consumed phi pair
-        }
-    }
-    PRISM_STAMP(2);
-    TileSave sv{ps.save ? a.ws.mu1 : nullptr, a.ws.rstd1, ps.save ? a.ws.pre1 : nullptr, ps.save ? a.ws.xhat2 : nullptr,
-                a.ws.rstd2, (int64_t)r0};
-    tile_trunk_head(a, tp, sv, ytile, h1, part, bt, ps.z_out + (int64_t)r0 * A, A);
-    if (!a.loss_in_fwd) return;
-    // ---- fused loss: the next-state tile(s) of these samples publish, the current-state tile consumes.
-    // Launch order puts every publisher at a lower workgroup index than its consumer, so a waiting
-    // consumer never holds a CU that its publisher still needs.
-    __syncthreads();                     // all rows of this tile are out (the barrier waits for vmcnt(0))
-    PRISM_STAMP(32);
-    if (ps.loss_role == 1) {
-        if (tid == 0) __hip_atomic_fetch_add(&a.ws.loss_flag[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (ps.loss_role == 2) {
-        iqn_loss_tile(a, r0, smem, &a.ws.loss_flag[tile], (unsigned)a.loss_in_fwd);
-        PRISM_STAMP(33);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// loss: one workgroup (8 waves) per sample.  Wave 0 evaluates the pairwise quantile-Huber tile
-// while every wave already has the saved activations of its rows in flight; then the T
-// current-state rows are back-propagated through head + LayerNorm(128), rows strided over waves.
-// T, T' must divide 64.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_loss[LOSS_LDS_FLOATS];
-    iqn_loss_sample(a, blockIdx.x, s_loss, false);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -871,15 +426,17 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
 // Each wave walks a contiguous run of 16-row tiles; everything a tile needs comes straight from
 // global/L2 into registers, LDS only transposes the two operands that are needed k-major.
 // ------------------------------------------------------------------------------------------
-constexpr int BWD_WAVE_LDS = 16 * CS + 16 * HS;     // floats per wave (cos tile + dpre1 tile)
-constexpr int BWD_ACC = 16 + 32 + 3;                // accumulators reduced across waves
+__host__ __device__ constexpr int bwd_wave_lds(int H) { return 16 * CS + 16 * (H + 4); }   // floats per wave (cos tile + dpre1 tile)
+__host__ __device__ constexpr int bwd_acc(int H) { return 16 + H / 4 + 3; }                 // accumulators reduced across waves
 // conv-backward partials ride along in the tile loop (IQN-only models: d e[b][n] is final per
 // (sample, column) right there).  The lanes that hold one (sample, position) value -- `share` of
 // them: 2 for T = 8, 4 for T >= 16 -- split the input channels; each lane owns all 9 kernel taps
 // of C/share channels in registers.
 constexpr int BWD_CONV_TAPS = 18;                   // taps per lane: 9 * C / share
 constexpr int BWD_CONV_ROW = 96;                    // floats per partial row: 9C taps (C <= 10) + bias
-constexpr int BWD_MAIN_LDS = 4 * BWD_ACC * 64 > 4 * (16 * CS + 16 * HS) ? 4 * BWD_ACC * 64 : 4 * (16 * CS + 16 * HS);
+__host__ __device__ constexpr int bwd_main_lds(int H) {
+    return 4 * bwd_acc(H) * 64 > 4 * bwd_wave_lds(H) ? 4 * bwd_acc(H) * 64 : 4 * bwd_wave_lds(H);
+}
 constexpr int BWD_CONV_PRE4 = 12;                   // float4 registers per lane staging the wave's observation rows
 __host__ __device__ inline int bwd_conv_share(int T) { return T == 4 ? 1 : (T == 8 ? 2 : 4); }
 // samples one wave may own (its observation rows are staged in LDS: 4 image rows x 10 x C floats each)
@@ -888,18 +445,21 @@ __host__ __device__ inline int bwd_conv_lds_floats(int B, int C, int n_chunks) {
     return 4 * BWD_CONV_ROW + 4 * bwd_conv_spw(B, n_chunks) * 40 * C;
 }
 __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propagate_grad, int T, int C, int B,
-                                            int n_chunks) {
+                                            int n_chunks, int H) {
     const int share = bwd_conv_share(T);
     return use_iqn && n_heads == 0 && propagate_grad && C % share == 0 && 9 * (C / share) <= BWD_CONV_TAPS &&
            C / share <= 2 && (C / share == 1 || C % 2 == 0) &&      // 1 channel, or an aligned pair, per lane
            9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE4 * 64 &&
-           (BWD_MAIN_LDS + bwd_conv_lds_floats(B, C, n_chunks)) * 4 <= 76 * 1024;     // two workgroups per CU
+           (bwd_main_lds(H) + bwd_conv_lds_floats(B, C, n_chunks)) * 4 <= 76 * 1024;     // two workgroups per CU
 }
 #ifndef BWD_CHUNKS
 #define BWD_CHUNKS 8
 #endif
 
-__global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
+template <int H, bool LN>
+__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
+    constexpr int NHT = H / 16, HS = H + 4, BWD_WAVE_LDS = bwd_wave_lds(H), BWD_ACC = bwd_acc(H), BWD_MAIN_LDS = bwd_main_lds(H);
+    constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);     // slab: phi_w | phi_b | [ln1_g | ln1_b] | w1
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
@@ -946,21 +506,21 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) wphi[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
     }
-    float w1f[32];    // B operand of dX: W1[h = 16q + 4g + jj][n]
+    float w1f[4 * NHT];    // B operand of dX: W1[h = 16q + 4g + jj][n]
     {
         const float *src = P + a.off.iqn_w1 + n;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < NHT; ++q)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) w1f[q * 4 + jj] = src[(int64_t)(16 * q + 4 * g + jj) * E_DIM];
     }
-    const float bphi = P[a.off.phi_b + n], g1 = P[a.off.iqn_ln1_g + n], be1 = P[a.off.iqn_ln1_b + n];
+    const float bphi = P[a.off.phi_b + n], g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
 
-    f32x4 accWphi[4], accW1[8];
+    f32x4 accWphi[4], accW1[NHT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) accWphi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
 
 #pragma unroll
@@ -972,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
     // operands of one 16-row tile (fetching a tile ahead was tried twice and loses: the registers it
     // costs matter more than the latency it hides with two workgroups per CU)
     struct TileIn {
-        float4 ac[4], ad[8];     // A fragments: cos rows / dpre1 rows (row = r0 + j, k = 16q + 4g + jj)
+        float4 ac[4], ad[NHT];   // A fragments: cos rows / dpre1 rows (row = r0 + j, k = 16q + 4g + jj)
         float4 mu, rs, c1, c2;   // row scalars of the D-layout rows 4g..4g+3
         float ev;
         int bsm;
@@ -982,15 +542,20 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         const float *src = a.ws.cosb + (int64_t)(r0 + j) * K_BASIS + 4 * g;
 #pragma unroll
         for (int q = 0; q < 4; ++q) t.ac[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-        const float *sd = a.ws.dpre1 + (int64_t)(r0 + j) * H_DIM + 4 * g;
+        const float *sd = a.ws.dpre1 + (int64_t)(r0 + j) * H + 4 * g;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t.ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
+        for (int q = 0; q < NHT; ++q) t.ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
         const int rb = r0 + 4 * g;
         t.bsm = rb / T;
-        t.mu = *reinterpret_cast<const float4 *>(a.ws.mu1 + rb);
-        t.rs = *reinterpret_cast<const float4 *>(a.ws.rstd1 + rb);
-        t.c1 = *reinterpret_cast<const float4 *>(a.ws.c1 + rb);
-        t.c2 = *reinterpret_cast<const float4 *>(a.ws.c2 + rb);
+        if (LN) {
+            t.mu = *reinterpret_cast<const float4 *>(a.ws.mu1 + rb);
+            t.rs = *reinterpret_cast<const float4 *>(a.ws.rstd1 + rb);
+            t.c1 = *reinterpret_cast<const float4 *>(a.ws.c1 + rb);
+            t.c2 = *reinterpret_cast<const float4 *>(a.ws.c2 + rb);
+        } else {
+            t.mu = t.c1 = t.c2 = float4{0.f, 0.f, 0.f, 0.f};
+            t.rs = float4{1.f, 1.f, 1.f, 1.f};
+        }
         t.ev = a.ws.e_cur[(int64_t)t.bsm * E_DIM + n];
     };
     auto process_tile = [&](const TileIn &t, int ti) {
@@ -999,23 +564,23 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&cosl[j * CS + 16 * q + 4 * g]) = t.ac[q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = t.ad[q];
+        for (int q = 0; q < NHT; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = t.ad[q];
         const int bsm = t.bsm;
         const float ev = t.ev;
         // phi columns and dX columns: three independent MFMA chains interleaved
         f32x4 aphi = {0.f, 0.f, 0.f, 0.f}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            aphi = mfma16(t.ac[q].x, wphi[q].x, aphi);
+        for (int q = 0; q < NHT / 2; ++q) {
+            if (q < 4) aphi = mfma16(t.ac[q & 3].x, wphi[q & 3].x, aphi);
             adx = mfma16(t.ad[2 * q].x, w1f[8 * q + 0], adx);
             adx2 = mfma16(t.ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
-            aphi = mfma16(t.ac[q].y, wphi[q].y, aphi);
+            if (q < 4) aphi = mfma16(t.ac[q & 3].y, wphi[q & 3].y, aphi);
             adx = mfma16(t.ad[2 * q].y, w1f[8 * q + 1], adx);
             adx2 = mfma16(t.ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
-            aphi = mfma16(t.ac[q].z, wphi[q].z, aphi);
+            if (q < 4) aphi = mfma16(t.ac[q & 3].z, wphi[q & 3].z, aphi);
             adx = mfma16(t.ad[2 * q].z, w1f[8 * q + 2], adx);
             adx2 = mfma16(t.ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
-            aphi = mfma16(t.ac[q].w, wphi[q].w, aphi);
+            if (q < 4) aphi = mfma16(t.ac[q & 3].w, wphi[q & 3].w, aphi);
             adx = mfma16(t.ad[2 * q].w, w1f[8 * q + 3], adx);
             adx2 = mfma16(t.ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
         }
@@ -1028,12 +593,12 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         for (int r = 0; r < 4; ++r) {
             const float phi = fmaxf(aphi[r] + bphi, 0.f);
             const float h0 = phi * ev;
-            const float xhat = (h0 - muv[r]) * rsv[r];
-            xv[r] = xhat * g1 + be1;                  // LN output (B operand of dW1)
+            const float xhat = LN ? (h0 - muv[r]) * rsv[r] : h0;
+            xv[r] = LN ? xhat * g1 + be1 : h0;        // trunk input (B operand of dW1)
             const float dX = adx[r] + adx2[r];
             s_dg += dX * xhat;
             s_db += dX;
-            const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
+            const float dh0 = LN ? rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM))) : dX;
             dep += dh0 * phi;
             const float dphi = (phi > 0.f) ? dh0 * ev : 0.f;
             dpp[r] = dphi;
@@ -1064,11 +629,11 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         // The 12 LDS operands of a k-step are read as ONE batch, one k-step ahead of the MFMAs that
         // use them (left to itself the compiler reads two values, waits, issues two MFMAs, ...: the
         // matrix pipe then idles for an LDS round trip every other instruction).
-        float cv[2][4], dv[2][8];
+        float cv[2][4], dv[2][NHT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) cv[0][kt] = cosl[(4 * g) * CS + 16 * kt + j];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) dv[0][mt] = dpl[(4 * g) * HS + 16 * mt + j];
+        for (int mt = 0; mt < NHT; ++mt) dv[0][mt] = dpl[(4 * g) * HS + 16 * mt + j];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1076,13 +641,13 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) cv[(r + 1) & 1][kt] = cosl[(4 * g + r + 1) * CS + 16 * kt + j];
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) dv[(r + 1) & 1][mt] = dpl[(4 * g + r + 1) * HS + 16 * mt + j];
+                for (int mt = 0; mt < NHT; ++mt) dv[(r + 1) & 1][mt] = dpl[(4 * g + r + 1) * HS + 16 * mt + j];
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the read batch ahead of this k-step's MFMAs
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) accWphi[kt] = mfma16(dpp[r], cv[r & 1][kt], accWphi[kt]);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) accW1[mt] = mfma16(dv[r & 1][mt], xv[r], accW1[mt]);
+            for (int mt = 0; mt < NHT; ++mt) accW1[mt] = mfma16(dv[r & 1][mt], xv[r], accW1[mt]);
         }
         // conv taps of (sample bsm, channel cs>>2, output position (y0 + (j>>3), j&7)); LDS reads of
         // this wave's own earlier writes need no barrier
@@ -1125,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[(kt * 4 + r) * 64] = accWphi[kt][r];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < NHT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[(16 + mt * 4 + r) * 64] = accW1[mt][r];
         // column sums: fold the 4 row groups (lanes j, j+16, j+32, j+48)
@@ -1135,12 +700,12 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
         s_db += __shfl_xor(s_db, 32, 64);
         s_dbphi += __shfl_xor(s_dbphi, 16, 64);
         s_dbphi += __shfl_xor(s_dbphi, 32, 64);
-        mine[48 * 64] = s_dg;
-        mine[49 * 64] = s_db;
-        mine[50 * 64] = s_dbphi;
+        mine[(16 + 4 * NHT) * 64] = s_dg;
+        mine[(17 + 4 * NHT) * 64] = s_db;
+        mine[(18 + 4 * NHT) * 64] = s_dbphi;
     }
     __syncthreads();
-    float *slab = a.ws.slabs + (int64_t)rc * SLAB;
+    float *slab = a.ws.slabs + (int64_t)rc * a.slab;
     // slot = w + 4 i for this thread (256 threads = 4 slots of 64 lanes per sweep): the slot's register
     // index r is the wave number, its tile index the sweep number -- affine addresses, no div/mod
     auto fold4 = [&](int slot) {
@@ -1158,19 +723,18 @@ __global__ __launch_bounds__(256, 2) void iqn_bwd_kernel(IqnArgs a) {
     }
     {
         // accW1[mt][r = w]: row h = 16*mt + 4*g + r, col n = cs*16 + j
-        float *dst = slab + (int64_t)(E_DIM * K_BASIS + 3 * E_DIM) + (int64_t)(4 * g + w) * E_DIM + cs * 16 + j;
-        float v[8];
+        float *dst = slab + (int64_t)SLAB_W1 + (int64_t)(4 * g + w) * E_DIM + cs * 16 + j;
+        float v[NHT];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) v[mt] = fold4(16 + w + 4 * mt);
+        for (int mt = 0; mt < NHT; ++mt) v[mt] = fold4(16 + w + 4 * mt);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) __builtin_nontemporal_store(v[mt], dst + (int64_t)16 * mt * E_DIM);
+        for (int mt = 0; mt < NHT; ++mt) __builtin_nontemporal_store(v[mt], dst + (int64_t)16 * mt * E_DIM);
     }
     if (w < 3 && g == 0) {
-        const float v = fold4(48 + w);
+        const float v = fold4(16 + 4 * NHT + w);
         const int nn = cs * 16 + j;
-        if (w == 0) slab[E_DIM * K_BASIS + E_DIM + nn] = v;           // d ln1_g
-        else if (w == 1) slab[E_DIM * K_BASIS + 2 * E_DIM + nn] = v;  // d ln1_b
-        else slab[E_DIM * K_BASIS + nn] = v;                          // d phi_b
+        if (w == 2) slab[E_DIM * K_BASIS + nn] = v;                   // d phi_b
+        else if (LN) slab[E_DIM * K_BASIS + (1 + w) * E_DIM + nn] = v;   // d ln1_g (w = 0), d ln1_b (w = 1)
     }
     PRISM_STAMP(12);
     if (!n_mine) return;
@@ -1427,13 +991,14 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
 __device__ __forceinline__ void small_tensor_block(const IqnArgs &a, int slice, float &sq, float *pool) {
     const float *P = a.params;
     float *gr = a.grads;
-    SmallIo io{P + a.off.iqn_w2, P + a.off.iqn_ln2_g, P + a.off.iqn_ln2_b, P + a.off.iqn_b1, P + a.off.iqn_b2,
-               gr + a.off.iqn_w2, gr + a.off.iqn_ln2_g, gr + a.off.iqn_ln2_b, gr + a.off.iqn_b1, gr + a.off.iqn_b2,
-               0.f, false, a.ws.lossw, H_DIM};
+    const bool ln = a.ln != 0;
+    SmallIo io{P + a.off.iqn_w2, ln ? P + a.off.iqn_ln2_g : nullptr, ln ? P + a.off.iqn_ln2_b : nullptr, P + a.off.iqn_b1, P + a.off.iqn_b2,
+               gr + a.off.iqn_w2, ln ? gr + a.off.iqn_ln2_g : nullptr, ln ? gr + a.off.iqn_ln2_b : nullptr, gr + a.off.iqn_b1, gr + a.off.iqn_b2,
+               0.f, false, a.ws.lossw, a.Hi};
     float lsum = 0.f;
     small_fold_block(a, slice, sq, pool, io,
                      [&](int b, int h, bool want_d) {
-                         return make_float3(a.ws.Sb[(int64_t)b * H_DIM + h], a.ws.Pb[(int64_t)b * H_DIM + h],
+                         return make_float3(a.ws.Sb[(int64_t)b * a.Hi + h], a.ws.Pb[(int64_t)b * a.Hi + h],
                                             want_d ? a.ws.Db[b] : 0.f);
                      },
                      &lsum);

@@ -6,7 +6,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <type_traits>
+#include <utility>
+
 #include "step_kernels.h"
+#include "fwd_kernels.h"
 
 namespace prism {
 
@@ -149,24 +155,24 @@ struct Carver {
 
 static constexpr int N_CHUNKS = BWD_CHUNKS;
 
+static bool width_ok(int h) { return h == 128 || h == 256; }
+
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
     if (d->embed_dim != E_DIM) return PRISM_ERR_UNSUPPORTED;
-    if (d->use_iqn && !d->use_layer_norm) return PRISM_ERR_UNSUPPORTED;
     if (d->use_iqn) {
-        if (d->n_basis != K_BASIS || d->iqn_layers != 1 || d->iqn_width != H_DIM) return PRISM_ERR_UNSUPPORTED;
+        if (d->n_basis != K_BASIS || d->iqn_layers != 1 || !width_ok(d->iqn_width)) return PRISM_ERR_UNSUPPORTED;
         if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
         if ((B * d->n_tau) % 16 || (B * d->n_tau_next) % 16) return PRISM_ERR_UNSUPPORTED;
     }
     if (d->n_heads != 0) {
-        // ensemble / DQN heads of the form LN -> Linear(1024,128) -> ReLU -> LN -> Linear(128,A)
+        // ensemble / DQN heads of the form [LN] -> Linear(1024,H) -> ReLU -> [LN] -> Linear(H,A)
         if (d->head_layers == 1) {
             // single Linear(1024 -> A) DQN head, with or without LayerNorm, no IQN beside it
             if (d->n_heads != 1 || d->use_iqn) return PRISM_ERR_UNSUPPORTED;
         } else {
-            if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || d->head_width != H_DIM ||
-                !d->use_layer_norm)
+            if (d->n_heads < 0 || d->n_heads > Q_MAX_HEADS || d->head_layers != 2 || !width_ok(d->head_width))
                 return PRISM_ERR_UNSUPPORTED;
             if (B % 16) return PRISM_ERR_UNSUPPORTED;
         }
@@ -176,23 +182,33 @@ static int iqn_supported(const prism_model_dims *d, int32_t B) {
     return PRISM_OK;
 }
 
+static int iqn_width(const prism_model_dims &d) { return d.use_iqn ? d.iqn_width : 128; }
+static int head_width(const prism_model_dims &d) { return d.n_heads && d.head_layers == 2 ? d.head_width : 128; }
+
+// the IQN loss finishes inside the forward tiles (kind 2) when current- and next-state rows of a sample run
+// through the SAME weights (no target network) and a 16-row tile holds whole samples (2 T <= 16)
+static int local_loss(const prism_model_dims &d) {
+    return d.use_iqn && !d.has_target && d.n_tau_next == d.n_tau && d.n_tau <= 8 ? 1 : 0;
+}
 
 static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws, float **tau_buf, float **dl_buf) {
     Carver c(base);
     const size_t R = (size_t)B * d->n_tau, Rn = (size_t)B * d->n_tau_next, A = d->n_actions;
     const size_t maxT = d->n_tau > d->n_tau_next ? d->n_tau : d->n_tau_next;
+    const size_t Hi = iqn_width(*d), Hq = head_width(*d);
+    const int ln = d->use_layer_norm;
     IqnWs w;
     w.ticket = (unsigned int *)c.f(4);     // first 16 bytes: the self-resetting tickets (zeroed once by the caller)
     w.e_cur = c.f((size_t)B * E_DIM);
     w.e_next = c.f((size_t)B * E_DIM);
-    w.uv = c.f(2 * H_DIM);
-    w.wpk[0] = c.f(PACK_FLOATS);
-    w.wpk[1] = c.f(PACK_FLOATS);
+    w.uv = c.f(4 * Hi);
+    w.wpk[0] = c.f(iqn_pack_floats((int)Hi));
+    w.wpk[1] = c.f(iqn_pack_floats((int)Hi));
     w.cosb = c.f(R * K_BASIS);
     w.mu1 = c.f(R);
     w.rstd1 = c.f(R);
-    w.pre1 = c.f(R * H_DIM);
-    w.xhat2 = c.f(R * H_DIM);
+    w.pre1 = c.f(R * Hi);
+    w.xhat2 = c.f(R * Hi);
     w.rstd2 = c.f(R);
     w.zcur = c.f(R * A);
     w.zon = c.f(Rn * A);
@@ -200,13 +216,13 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.dq = c.f(R);
     w.c1 = c.f(R);
     w.c2 = c.f(R);
-    w.dpre1 = c.f(R * H_DIM);
-    w.Sb = c.f((size_t)B * H_DIM);
-    w.Pb = c.f((size_t)B * H_DIM);
+    w.dpre1 = c.f(R * Hi);
+    w.Sb = c.f((size_t)B * Hi);
+    w.Pb = c.f((size_t)B * Hi);
     w.Db = c.f(B);
     w.lossw = c.f(B);
     w.de_iqn = c.f((size_t)B * E_DIM);
-    w.slabs = c.f((size_t)N_CHUNKS * SLAB);
+    w.slabs = c.f((size_t)N_CHUNKS * iqn_slab_floats((int)Hi, ln));
     {
         const size_t post_rows = (size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW;
         const size_t bwd_rows = (size_t)(E_DIM / 16) * N_CHUNKS * BWD_CONV_ROW;
@@ -217,13 +233,12 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.normpart = c.f(NORM_SLOTS);
     w.sib = c.f((size_t)TREE_MAX_LEVELS * B * 2);
     w.wb_plan = c.f((size_t)B * 4);
-    w.loss_flag = (unsigned int *)c.f(R / 16 + 4);
     {
         const size_t Hd = d->n_heads, RQ = Hd * (size_t)B;
         w.q_mu1 = c.f(RQ);
         w.q_rstd1 = c.f(RQ);
-        w.q_pre1 = c.f(RQ * H_DIM);
-        w.q_xhat2 = c.f(RQ * H_DIM);
+        w.q_pre1 = c.f(RQ * Hq);
+        w.q_xhat2 = c.f(RQ * Hq);
         w.q_rstd2 = c.f(RQ);
         w.zq_cur = c.f(RQ * A);
         w.zq_on = c.f(RQ * A);
@@ -231,15 +246,14 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_dq = c.f(RQ);
         w.q_c1 = c.f(RQ);
         w.q_c2 = c.f(RQ);
-        w.q_dpre1 = c.f(RQ * H_DIM);
-        w.q_Sb = w.q_Pb = w.q_Db = nullptr;
+        w.q_dpre1 = c.f(RQ * Hq);
         w.q_lossw = c.f(B);
-        w.q_uv = c.f(Hd * 2 * H_DIM);
+        w.q_uv = c.f(2 * Hd * 2 * Hq);
         w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
-        w.q_wpk[0] = c.f(Hd * (size_t)H_DIM * E_DIM);
-        w.q_wpk[1] = c.f(d->has_target ? Hd * (size_t)H_DIM * E_DIM : 0);
+        w.q_wpk[0] = c.f(Hd * Hq * E_DIM);
+        w.q_wpk[1] = c.f(d->has_target ? Hd * Hq * E_DIM : 0);
         w.de_q = c.f(Hd * (size_t)B * E_DIM);      // (one slot for the single-Linear DQN head)
-        w.q_slabs = c.f(Hd * (size_t)Q_SLAB);
+        w.q_slabs = c.f(Hd * (size_t)q_slab_floats((int)Hq, ln));
     }
     float *tb = c.f(3 * maxT * B);
     float *db = c.f(B);
@@ -268,8 +282,8 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(ld != nullptr, "null descriptor");
     if (iqn_supported(&ld->dims, ld->batch) != PRISM_OK) {
         set_error("prism_learner: model dims / batch not covered by the HIP kernels "
-                  "(need LayerNorm on, E=1024; IQN: K=64, H=128, one trunk layer, T in {4,8,16,32,64}, B*T %% 16 == 0; "
-                  "Q heads: two layers of width 128, B %% 16 == 0)");
+                  "(need E=1024; IQN: K=64, H in {128,256}, one trunk layer, T in {4,8,16,32,64}, B*T %% 16 == 0; "
+                  "Q heads: one layer, or two layers of width 128/256 with B %% 16 == 0)");
         return PRISM_ERR_UNSUPPORTED;
     }
     PRISM_CHECK_ARG(ld->params && ld->grads && ld->adam_m && ld->adam_v && ld->adam_step, "null parameter buffers");
@@ -284,8 +298,11 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(ld->dims.n_heads == 0 || (ld->off.head_base >= 0 && ld->off.h_w1 >= 0 && ld->off.h_b1 >= 0),
                     "Q-head parameter offsets missing");
     PRISM_CHECK_ARG(ld->dims.n_heads == 0 || ld->dims.head_layers == 1 ||
-                        (ld->off.h_w2 >= 0 && ld->off.h_ln1_g >= 0 && ld->off.h_ln2_g >= 0),
+                        (ld->off.h_w2 >= 0 && (!ld->dims.use_layer_norm || (ld->off.h_ln1_g >= 0 && ld->off.h_ln2_g >= 0))),
                     "two-layer Q-head parameter offsets missing");
+    PRISM_CHECK_ARG(!ld->dims.use_iqn || (ld->off.iqn_w1 >= 0 && ld->off.iqn_w2 >= 0 &&
+                                          (!ld->dims.use_layer_norm || (ld->off.iqn_ln1_g >= 0 && ld->off.iqn_ln2_g >= 0))),
+                    "IQN parameter offsets missing");
     PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
                     "null batch arrays");
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
@@ -296,17 +313,16 @@ static int check_learner(const prism_learner_desc *ld) {
 // beside clip + Adam (back launch, 256-thread workgroups: one leaf per thread)
 static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 256; }
 
-// the IQN loss runs in the tail of the current-state tiles of tile_fwd when a 16-row tile holds whole
-// samples and the next-state rows of those samples form the tile of the same index
-static int loss_in_fwd(const prism_model_dims &d) {
-    return d.use_iqn && d.n_tau <= 16 && 16 % d.n_tau == 0 && d.n_tau_next == d.n_tau ? 1 : 0;
+static bool conv_in_bwd(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS, iqn_width(d));
 }
 
 static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(d.in_channels);
-    return post_blocks(ld->batch, d.use_iqn, d.n_heads,
-                       bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS));
+    return post_blocks(ld->batch, d.use_iqn, d.n_heads, conv_in_bwd(ld), iqn_slab_floats(iqn_width(d), d.use_layer_norm),
+                       q_slab_floats(head_width(d), d.use_layer_norm), iqn_width(d), head_width(d));
 }
 
 static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
@@ -320,11 +336,16 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.C = d.in_channels;
     a.T = d.n_tau;
     a.Tn = d.n_tau_next;
+    a.Hi = iqn_width(d);
+    a.Hq = head_width(d);
+    a.ln = d.use_layer_norm;
+    a.slab = iqn_slab_floats(a.Hi, a.ln);
+    a.q_slab = q_slab_floats(a.Hq, a.ln);
     a.n_chunks = N_CHUNKS;
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
-    a.conv_in_bwd = bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS);
+    a.conv_in_bwd = conv_in_bwd(ld);
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;
     a.use_iqn = d.use_iqn;
@@ -355,38 +376,80 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.out_td = ld->out_td;
     a.out_scalars = ld->out_scalars;
     a.grads = ld->grads;
-    // passes, in the reference's tau draw order (iqn_model.py:104,112-126)
+    // passes; the tau draws are tied to stream_id in the reference's draw order (iqn_model.py:104,112-126)
     int np = 0;
-    const float *pk0 = a.ws.wpk[0], *pk1 = a.ws.wpk[1];
+    const float *uv0 = a.ws.uv, *uv1 = a.ws.uv + 2 * a.Hi;
     if (d.use_iqn) {
-        // launch order: next-state passes first, the current-state pass last (fused loss, see tile_fwd);
-        // the tau draws are tied to stream_id, not to this order
-        const int fuse = loss_in_fwd(d);
-        a.loss_in_fwd = 0;
-        if (!d.has_target || d.double_q) {
-            a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_online, a.ws.zon,
-                                   d.n_tau_next, B * d.n_tau_next / 16, 0, 1, 0, fuse ? 1 : 0};
-            a.loss_in_fwd += fuse;
+        a.local_loss = local_loss(d);
+        if (a.local_loss) {
+            // one pass of mixed tiles: each holds whole samples (T current-state + T next-state rows)
+            IqnPass p;
+            memset(&p, 0, sizeof(p));
+            p.params = ld->params;
+            p.wpk = a.ws.wpk[0];
+            p.uv = uv0;
+            p.e = a.ws.e_cur;
+            p.e2 = a.ws.e_next;
+            p.tau_in = ld->tau_cur;
+            p.tau_in2 = ld->tau_next_online;
+            p.z_out = a.ws.zcur;
+            p.z_out2 = a.ws.zon;
+            p.T = d.n_tau;
+            p.n_tiles = B * 2 * d.n_tau / 16;
+            p.save = 1;
+            p.stream_id = 0;
+            p.kind = 2;
+            a.pass[np++] = p;
+            a.ws.ztg = a.ws.zon;
+        } else {
+            auto iqn_pass = [&](const float *params, int set, const float *e, const float *tau, float *z, int T, int save,
+                                int sid) {
+                IqnPass p;
+                memset(&p, 0, sizeof(p));
+                p.params = params;
+                p.wpk = a.ws.wpk[set];
+                p.uv = set ? uv1 : uv0;
+                p.e = e;
+                p.tau_in = tau;
+                p.z_out = z;
+                p.T = T;
+                p.n_tiles = B * T / 16;
+                p.save = save;
+                p.stream_id = sid;
+                p.kind = 0;
+                return p;
+            };
+            a.pass[np++] = iqn_pass(ld->params, 0, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau, 1, 0);
+            if (!d.has_target || d.double_q)
+                a.pass[np++] = iqn_pass(ld->params, 0, a.ws.e_next, ld->tau_next_online, a.ws.zon, d.n_tau_next, 0, 1);
+            if (d.has_target)
+                a.pass[np++] = iqn_pass(ld->target_params, 1, a.ws.e_next, ld->tau_next_target, a.ws.ztg, d.n_tau_next, 0, 2);
+            if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
+            else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
         }
-        if (d.has_target) {
-            a.pass[np++] = IqnPass{ld->target_params, pk1, pk1 + E_DIM * K_BASIS, a.ws.e_next, ld->tau_next_target,
-                                   a.ws.ztg, d.n_tau_next, B * d.n_tau_next / 16, 0, 2, 0, fuse ? 1 : 0};
-            a.loss_in_fwd += fuse;
-        }
-        a.pass[np++] = IqnPass{ld->params, pk0, pk0 + E_DIM * K_BASIS, a.ws.e_cur, ld->tau_cur, a.ws.zcur, d.n_tau,
-                               B * d.n_tau / 16, 1, 0, 0, fuse ? 2 : 0};
-        if (!d.has_target) a.ws.ztg = a.ws.zon;            // bootstrap from self
-        else if (!d.double_q) a.ws.zon = a.ws.ztg;         // DQN-style: target picks the action too
     }
     if (d.n_heads > 0 && d.head_layers == 2) {
         // Q-head tiles: (B/16) x heads per pass; same online/target selection (q_ensemble.py:62-68)
         const int nt = (B / 16) * d.n_heads;
-        a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_cur, nullptr, a.ws.zq_cur, 1, nt, 1, 0, 1, 0};
-        if (!d.has_target || d.double_q)
-            a.pass[np++] = IqnPass{ld->params, nullptr, a.ws.q_wpk[0], a.ws.e_next, nullptr, a.ws.zq_on, 1, nt, 0, 1, 1, 0};
-        if (d.has_target)
-            a.pass[np++] = IqnPass{ld->target_params, nullptr, a.ws.q_wpk[1], a.ws.e_next, nullptr, a.ws.zq_tg, 1, nt, 0, 2,
-                                   1, 0};
+        const float *quv0 = a.ws.q_uv, *quv1 = a.ws.q_uv + (size_t)d.n_heads * 2 * a.Hq;
+        auto q_pass = [&](const float *params, int set, const float *e, float *z, int save, int sid) {
+            IqnPass p;
+            memset(&p, 0, sizeof(p));
+            p.params = params;
+            p.wpk = a.ws.q_wpk[set];
+            p.uv = set ? quv1 : quv0;
+            p.e = e;
+            p.z_out = z;
+            p.T = 1;
+            p.n_tiles = nt;
+            p.save = save;
+            p.stream_id = sid;
+            p.kind = 1;
+            return p;
+        };
+        a.pass[np++] = q_pass(ld->params, 0, a.ws.e_cur, a.ws.zq_cur, 1, 0);
+        if (!d.has_target || d.double_q) a.pass[np++] = q_pass(ld->params, 0, a.ws.e_next, a.ws.zq_on, 0, 1);
+        if (d.has_target) a.pass[np++] = q_pass(ld->target_params, 1, a.ws.e_next, a.ws.zq_tg, 0, 2);
         if (!d.has_target) a.ws.zq_tg = a.ws.zq_on;
         else if (!d.double_q) a.ws.zq_on = a.ws.zq_tg;
     }
@@ -417,6 +480,32 @@ static int adam_blocks(int64_t n) {
     return blocks < 1 ? 1 : blocks;
 }
 
+// template dispatch over the hidden width and LayerNorm on/off
+template <typename F>
+static void dispatch_hl(int H, int ln, F &&f) {
+    if (H == 128) {
+        if (ln) f(std::integral_constant<int, 128>{}, std::true_type{});
+        else f(std::integral_constant<int, 128>{}, std::false_type{});
+    } else {
+        if (ln) f(std::integral_constant<int, 256>{}, std::true_type{});
+        else f(std::integral_constant<int, 256>{}, std::false_type{});
+    }
+}
+
+// dynamic-LDS opt-in of the kernels that need more than 64 KB: once per device and instantiation
+static hipError_t set_max_lds(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
+
 extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream_) {
     int rc = check_learner(ld);
     if (rc) return rc;
@@ -424,61 +513,94 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     const int B = ld->batch;
     IqnArgs a;
     fill_iqn_args(ld, a);
-    int total_tiles = 0;
-    for (int i = 0; i < a.n_pass; ++i) total_tiles += a.pass[i].n_tiles;
+    hipError_t herr = hipSuccess;
 
-    static bool attr_set = false;
-    const size_t fwd_lds = TILE_FWD_LDS_FLOATS * sizeof(float);
-    const size_t bwd_lds = (size_t)(BWD_MAIN_LDS + (a.conv_in_bwd ? bwd_conv_lds_floats(B, a.C, N_CHUNKS) : 0)) * sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)iqn_tile_fwd_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd_lds);
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(tile_fwd, %zu): %s", fwd_lds, hipGetErrorString(e));
-            return PRISM_ERR_HIP;
-        }
-        e = hipFuncSetAttribute((const void *)qh_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(QB_LDS_FLOATS * sizeof(float)));
-        if (e != hipSuccess) {
-            set_error("hipFuncSetAttribute(qh_bwd): %s", hipGetErrorString(e));
-            return PRISM_ERR_HIP;
-        }
-        attr_set = true;
-    }
     if (!ld->embed_done) {
         ProfileScope ps_(K_EMBED, stream);
-        hipLaunchKernelGGL(iqn_embed_kernel,
-                           dim3(2 * B + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target, ld->dims.head_layers)),
-                           dim3(256),
-                           0, stream, a);
+        hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * B + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a);
         PRISM_CHECK_LAUNCH();
     }
-    if (total_tiles > 0) {
+    // forward tiles: one launch when every tile kind has the same hidden width, else one per kind
+    {
+        int n_iqn = 0, n_q = 0;
+        for (int i = 0; i < a.n_pass; ++i) (a.pass[i].kind == 1 ? n_q : n_iqn) += a.pass[i].n_tiles;
+        auto launch = [&](const IqnArgs &aa, int H, int tiles) {
+            dispatch_hl(H, aa.ln, [&](auto h, auto l) {
+                constexpr int HH = decltype(h)::value;
+                constexpr bool LL = decltype(l)::value;
+                const size_t lds = fw_lds_floats<HH>() * sizeof(float);
+                herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
+                if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(512), lds, stream, aa);
+            });
+        };
         ProfileScope ps_(K_TILE_FWD, stream);
-        hipLaunchKernelGGL(iqn_tile_fwd_kernel, dim3(total_tiles), dim3(512), fwd_lds, stream, a);
+        if (n_iqn && n_q && a.Hi != a.Hq) {
+            IqnArgs a1 = a, a2 = a;
+            a1.n_pass = a2.n_pass = 0;
+            for (int i = 0; i < a.n_pass; ++i) {
+                if (a.pass[i].kind == 1) a2.pass[a2.n_pass++] = a.pass[i];
+                else a1.pass[a1.n_pass++] = a.pass[i];
+            }
+            launch(a1, a.Hi, n_iqn);
+            launch(a2, a.Hq, n_q);
+        } else if (n_iqn + n_q > 0) {
+            launch(a, n_iqn ? a.Hi : a.Hq, n_iqn + n_q);
+        }
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(fwd_tile): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
         PRISM_CHECK_LAUNCH();
     }
     // losses first (TD errors final), then the backward kernels
-    if (ld->dims.use_iqn && !a.loss_in_fwd) {
+    if (ld->dims.use_iqn && !a.local_loss) {
         ProfileScope ps_(K_LOSS, stream);
-        hipLaunchKernelGGL(iqn_loss_kernel, dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
+        dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
+            hipLaunchKernelGGL((iqn_loss_kernel<decltype(h)::value, decltype(l)::value>), dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
+        });
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dims.n_heads > 0) {
         ProfileScope ps_(K_Q_FWD, stream);
-        if (ld->dims.head_layers == 1) hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(qh_loss_kernel, dim3(B), dim3(512), 0, stream, a);
+        if (ld->dims.head_layers == 1) {
+            hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
+        } else {
+            dispatch_hl(a.Hq, a.ln, [&](auto h, auto l) {
+                hipLaunchKernelGGL((qh_loss_kernel<decltype(h)::value, decltype(l)::value>), dim3(B), dim3(512), 0, stream, a);
+            });
+        }
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dims.use_iqn) {
         ProfileScope ps_(K_BWD, stream);
-        hipLaunchKernelGGL(iqn_bwd_kernel, dim3((E_DIM / 16) * N_CHUNKS), dim3(256), bwd_lds, stream, a);
+        dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
+            constexpr int HH = decltype(h)::value;
+            constexpr bool LL = decltype(l)::value;
+            const size_t lds = (size_t)(bwd_main_lds(HH) + (a.conv_in_bwd ? bwd_conv_lds_floats(B, a.C, N_CHUNKS) : 0)) * sizeof(float);
+            herr = set_max_lds((const void *)iqn_bwd_kernel<HH, LL>, lds);
+            if (herr == hipSuccess)
+                hipLaunchKernelGGL((iqn_bwd_kernel<HH, LL>), dim3((E_DIM / 16) * N_CHUNKS), dim3(256), lds, stream, a);
+        });
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(iqn_bwd): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2) {
         ProfileScope ps_(K_Q_BWD, stream);
-        hipLaunchKernelGGL(qh_bwd_kernel, dim3((E_DIM / 16) * ld->dims.n_heads), dim3(256), QB_LDS_FLOATS * sizeof(float), stream,
-                           a);
+        dispatch_hl(a.Hq, a.ln, [&](auto h, auto l) {
+            constexpr int HH = decltype(h)::value;
+            constexpr bool LL = decltype(l)::value;
+            const size_t lds = qb_lds_floats(HH) * sizeof(float);
+            herr = set_max_lds((const void *)qh_bwd_kernel<HH, LL>, lds);
+            if (herr == hipSuccess)
+                hipLaunchKernelGGL((qh_bwd_kernel<HH, LL>), dim3((E_DIM / 16) * ld->dims.n_heads), dim3(256), lds, stream, a);
+        });
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(qh_bwd): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
         PRISM_CHECK_LAUNCH();
     }
     {
@@ -583,8 +705,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     {
         ProfileScope ps_(K_FRONT, stream);
         hipLaunchKernelGGL(step_front_kernel,
-                           dim3(ld->batch + front_extra_blocks(ld->dims.use_iqn, ld->dims.n_heads, ld->dims.has_target, ld->dims.head_layers)),
-                           dim3(256), 0, stream, a, *rp, f);
+                           dim3(ld->batch + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

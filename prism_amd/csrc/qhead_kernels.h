@@ -1,14 +1,14 @@
 // Q-ensemble (IDS) / 2-layer DQN heads: loss, backward and the block routines of their gradient
 // reduction.  Restates /root/reference/prism/agents/models/q_ensemble.py:44-92 for heads of the form
-//   LayerNorm(1024) -> Linear(1024 -> 128) -> ReLU -> LayerNorm(128) -> Linear(128 -> A)
-// (ffnn_model.py:61-76 with n_layers = 2).  The forward of a head tile is kind 1 of iqn_tile_fwd_kernel.
+//   [LayerNorm(1024)] -> Linear(1024 -> H) -> ReLU -> [LayerNorm(H)] -> Linear(H -> A),  H in {128, 256}
+// (ffnn_model.py:61-76 with n_layers = 2).  The forward of a head tile is kind 1 of fwd_tile_kernel.
 // Rows of all per-head workspace arrays are indexed  head * B + sample.
 #pragma once
 #include "iqn_kernels.h"
 
 namespace prism {
 
-constexpr int Q_SLAB = 2 * E_DIM + H_DIM * E_DIM;       // per head: ln1_g | ln1_b | w1
+__host__ __device__ inline int q_slab_floats(int H, int ln) { return (ln ? 2 * E_DIM : 0) + H * E_DIM; }   // per head: [ln1_g | ln1_b |] w1
 constexpr int Q_MAX_HEADS = 16;
 
 // Head tensors start at arbitrary float offsets of the flat parameter buffer (head stride 134 278
@@ -16,21 +16,26 @@ constexpr int Q_MAX_HEADS = 16;
 __device__ __forceinline__ float4 ld4u(const float *p) { return float4{p[0], p[1], p[2], p[3]}; }
 
 // ---- front-kernel roles -------------------------------------------------------------------------
-// packed W1 of head `hd` (same fragment order as the IQN trunk weight)
-__device__ __forceinline__ void pack_head_w1_block(const float *__restrict__ P, const prism_param_offsets &off,
+// stream-packed W1 (* ln1_g) of head `hd`: the IQN copy's layout without the phi slots (iqn_kernels.h)
+__device__ __forceinline__ void pack_head_w1_block(const float *__restrict__ P, const prism_param_offsets &off, int H, int ln,
                                                    float *__restrict__ pk, int hd, int blk, int tid) {
     const int r = blk * 256 + tid;               // packed float4 index within the head, < H*E/4
     const int lane = r & 63, li = lane & 15, g = lane >> 4;
-    const int q = (r >> 6) & 7, nt = (r >> 9) & 7, w = r >> 12;
-    const float *src = P + off.head_base + (int64_t)hd * off.head_stride + off.h_w1 +
-                       (int64_t)(16 * nt + li) * E_DIM + 128 * w + 16 * q + 4 * g;
-    reinterpret_cast<float4 *>(pk + (size_t)hd * H_DIM * E_DIM)[r] = ld4u(src);
+    const int NHT = H / 16, grp = r >> 6, step = grp / NHT, ht = grp - step * NHT;
+    const float *Ph = P + off.head_base + (int64_t)hd * off.head_stride;
+    const int n0 = 16 * step + 4 * g;
+    float4 v = ld4u(Ph + off.h_w1 + (int64_t)(16 * ht + li) * E_DIM + n0);
+    if (ln) {
+        const float4 gg = ld4u(Ph + off.h_ln1_g + n0);
+        v.x *= gg.x; v.y *= gg.y; v.z *= gg.z; v.w *= gg.w;
+    }
+    reinterpret_cast<float4 *>(pk + (size_t)hd * H * E_DIM)[r] = v;
 }
-constexpr int Q_PACK_BLOCKS_PER_HEAD = H_DIM * E_DIM / 4 / 256;   // 128
+__host__ __device__ inline int q_pack_blocks_per_head(int H) { return H * E_DIM / 4 / 256; }
 
-// u_h[hh] = sum_n W1_h[hh][n] g1_h[n],  v_h[hh] = sum_n W1_h[hh][n] beta1_h[n]   (one wave per (head, hh))
-__device__ __forceinline__ void q_uv_block(const IqnArgs &a, int hd, int hh, int lane) {
-    const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+// u_h[hh] = sum_n W1_h[hh][n] g1_h[n],  v_h[hh] = sum_n W1_h[hh][n] beta1_h[n]   (one wave per (set, head, hh))
+__device__ __forceinline__ void q_uv_block(const IqnArgs &a, int set, int hd, int hh, int lane) {
+    const float *Ph = (set ? a.target_params : a.params) + a.off.head_base + (int64_t)hd * a.off.head_stride;
     const float *W1 = Ph + a.off.h_w1 + (int64_t)hh * E_DIM, *g1 = Ph + a.off.h_ln1_g, *b1 = Ph + a.off.h_ln1_b;
     float su = 0.f, sv = 0.f;
 #pragma unroll
@@ -42,8 +47,9 @@ __device__ __forceinline__ void q_uv_block(const IqnArgs &a, int hd, int hh, int
     su = wave_sum(su);
     sv = wave_sum(sv);
     if (lane == 0) {
-        a.ws.q_uv[(hd * 2 + 0) * H_DIM + hh] = su;
-        a.ws.q_uv[(hd * 2 + 1) * H_DIM + hh] = sv;
+        float *uv = a.ws.q_uv + ((size_t)set * a.n_heads + hd) * 2 * a.Hq;
+        uv[hh] = su;
+        uv[a.Hq + hh] = sv;
     }
 }
 
@@ -105,26 +111,30 @@ __device__ __forceinline__ void stage_head_norms(const IqnArgs &a, float *s_part
 
 // ------------------------------------------------------------------------------------------
 // q loss: one workgroup (8 waves) per sample.  MSE against the n-step target per head, then the
-// head + LayerNorm(128) backward of the sample's row in every head.
+// head + LayerNorm(H) backward of the sample's row in every head.
 // ------------------------------------------------------------------------------------------
+template <int H, bool LN>
 __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
+    constexpr int KH = H / 64;
     __shared__ float s_zc[Q_MAX_HEADS * 16], s_zo[Q_MAX_HEADS * 16], s_zt[Q_MAX_HEADS * 16];
     __shared__ float s_dq[Q_MAX_HEADS], s_sq[Q_MAX_HEADS];
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, Hd = a.n_heads;
     // saved activations of this wave's rows (heads w, w + 8): in flight before the loss is known
-    float xa[2], xb[2], pa[2], pb[2], rs[2];
+    float xa[2][KH], pa[2][KH], rs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int hd = w + 8 * i;
+        rs[i] = 1.f;
         if (hd < Hd) {
             const int64_t r = (int64_t)hd * B + b;
-            xa[i] = a.ws.q_xhat2[r * H_DIM + lane];
-            xb[i] = a.ws.q_xhat2[r * H_DIM + 64 + lane];
-            pa[i] = a.ws.q_pre1[r * H_DIM + lane];
-            pb[i] = a.ws.q_pre1[r * H_DIM + 64 + lane];
-            rs[i] = a.ws.q_rstd2[r];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                xa[i][k] = a.ws.q_xhat2[r * H + 64 * k + lane];
+                pa[i][k] = a.ws.q_pre1[r * H + 64 * k + lane];
+            }
+            if (LN) rs[i] = a.ws.q_rstd2[r];
         }
     }
     const int act = (int)a.action[b];
@@ -172,32 +182,49 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         a.out_td[b] = a.use_iqn ? (a.out_dl[b] * 0.5f + ql * 0.5f) : fabsf(ql);
         if (b == 0) a.out_scalars[4] = theil;
     }
-    // head + LayerNorm(128) backward of row (head, b)
+    // head + LayerNorm(H) backward of row (head, b)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int hd = w + 8 * i;
         if (hd < Hd) {
             const int64_t r = (int64_t)hd * B + b;
             const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
-            const float *W2 = Ph + a.off.h_w2 + (int64_t)act * H_DIM, *g2 = Ph + a.off.h_ln2_g, *b1 = Ph + a.off.h_b1;
-            const float *uv = a.ws.q_uv + (size_t)hd * 2 * H_DIM;
-            const float w2a = W2[lane] * g2[lane], w2b = W2[lane + 64] * g2[lane + 64];
-            const float ua = uv[lane], ub = uv[lane + 64];
-            const float va = uv[H_DIM + lane] + b1[lane], vb = uv[H_DIM + lane + 64] + b1[lane + 64];
+            const float *W2 = Ph + a.off.h_w2 + (int64_t)act * H;
+            const float *uv = a.ws.q_uv + (size_t)hd * 2 * H;        // (online set)
             const float dq = s_dq[hd];
-            const float da = dq * w2a, db = dq * w2b;
-            const float m1 = wave_sum(da + db) * (1.0f / H_DIM);
-            const float m2 = wave_sum(da * xa[i] + db * xb[i]) * (1.0f / H_DIM);
-            float ga = rs[i] * (da - m1 - xa[i] * m2), gb = rs[i] * (db - m1 - xb[i] * m2);
-            ga = pa[i] > 0.f ? ga : 0.f;
-            gb = pb[i] > 0.f ? gb : 0.f;
-            a.ws.q_dpre1[r * H_DIM + lane] = ga;
-            a.ws.q_dpre1[r * H_DIM + 64 + lane] = gb;
-            const float c1 = wave_sum(ga * ua + gb * ub);
-            const float c2 = wave_sum(ga * (pa[i] - va) + gb * (pb[i] - vb));
+            float da[KH], ga[KH], ua[KH], va[KH], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const int h = 64 * k + lane;
+                const float w2 = LN ? W2[h] * Ph[a.off.h_ln2_g + h] : W2[h];
+                ua[k] = LN ? uv[h] : 0.f;
+                va[k] = (LN ? uv[H + h] : 0.f) + Ph[a.off.h_b1 + h];
+                da[k] = dq * w2;
+                m1 += da[k];
+                m2 += da[k] * xa[i][k];
+            }
+            if (LN) {
+                m1 = wave_sum(m1) * (1.0f / H);
+                m2 = wave_sum(m2) * (1.0f / H);
+            }
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) {
+                const float gv = LN ? rs[i] * (da[k] - m1 - xa[i][k] * m2) : da[k];
+                ga[k] = pa[i][k] > 0.f ? gv : 0.f;
+                a.ws.q_dpre1[r * H + 64 * k + lane] = ga[k];
+                c1 += ga[k] * ua[k];
+                c2 += ga[k] * (pa[i][k] - va[k]);
+            }
+            if (LN) {
+                c1 = wave_sum(c1);
+                c2 = wave_sum(c2);
+            }
             if (lane == 0) {
-                a.ws.q_c1[r] = c1;
-                a.ws.q_c2[r] = c2;
+                if (LN) {
+                    a.ws.q_c1[r] = c1;
+                    a.ws.q_c2[r] = c2;
+                }
                 a.ws.q_dq[r] = dq;
             }
         }
@@ -211,11 +238,14 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
 // its (head, column slice) outright), embedding gradient per head -> de_q[head][b][n] (summed over
 // heads where it is consumed, conv_bwd_partial_block).
 // ------------------------------------------------------------------------------------------
-constexpr int QB_ACC = 32 + 2;           // accumulators folded across the four waves
-constexpr int QB_STAGE = QB_ACC * 64;    // per-wave staging floats: dpre1 tile (16*HS = 2112) aliased with the fold buffer
-constexpr int QB_LDS_FLOATS = 4 * QB_STAGE;
+__host__ __device__ constexpr int qb_acc(int H) { return H / 4 + 2; }             // accumulators folded across the four waves
+__host__ __device__ constexpr int qb_stage(int H) { return qb_acc(H) * 64; }       // per-wave staging floats: dpre1 tile (16*(H+4)) aliased with the fold buffer
+__host__ __device__ constexpr int qb_lds_floats(int H) { return 4 * qb_stage(H); }
 
+template <int H, bool LN>
 __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
+    constexpr int NHT = H / 16, HS = H + 4, QB_ACC = qb_acc(H), QB_STAGE = qb_stage(H);
+    static_assert(16 * HS <= QB_STAGE, "dpre1 tile must fit the per-wave staging area");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
@@ -226,42 +256,43 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     float *dpl = smem + w * QB_STAGE;
     float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area after the barrier
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
-    float w1f[32];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n], gathered from the fragment-packed copy:
-    {                 // each (q, jj) load stays inside one contiguous 1 KB block instead of striding 4 KB rows
-        const float *pk = a.ws.q_wpk[0] + (size_t)hd * H_DIM * E_DIM;
-        const int wv = n >> 7, qn = (n >> 4) & 7, gp = (n >> 2) & 3, jn = n & 3;
+    float w1f[4 * NHT];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n]
+    {
+        const float *src = Ph + a.off.h_w1 + n;
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < NHT; ++q)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                w1f[q * 4 + jj] = pk[((((size_t)wv * 8 + q) * 8 + qn) * 64 + gp * 16 + 4 * g + jj) * 4 + jn];
+            for (int jj = 0; jj < 4; ++jj) w1f[q * 4 + jj] = src[(int64_t)(16 * q + 4 * g + jj) * E_DIM];
     }
-    const float g1 = Ph[a.off.h_ln1_g + n], be1 = Ph[a.off.h_ln1_b + n];
-    f32x4 accW1[8];
+    const float g1 = LN ? Ph[a.off.h_ln1_g + n] : 1.f, be1 = LN ? Ph[a.off.h_ln1_b + n] : 0.f;
+    f32x4 accW1[NHT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f;
     float *de_h = a.ws.de_q + (size_t)hd * B * E_DIM;
     for (int t = w; t < tiles_total; t += 4) {
         const int b0 = t * 16;
         const int64_t row0 = (int64_t)hd * B + b0;
-        float4 ad[8];
-        const float *sd = a.ws.q_dpre1 + (row0 + j) * H_DIM + 4 * g;
+        float4 ad[NHT];
+        const float *sd = a.ws.q_dpre1 + (row0 + j) * H + 4 * g;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
+        for (int q = 0; q < NHT; ++q) ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
+        for (int q = 0; q < NHT; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = ad[q];
         const int64_t rb = row0 + 4 * g;
-        const float4 mu = *reinterpret_cast<const float4 *>(a.ws.q_mu1 + rb);
-        const float4 rs = *reinterpret_cast<const float4 *>(a.ws.q_rstd1 + rb);
-        const float4 c1 = *reinterpret_cast<const float4 *>(a.ws.q_c1 + rb);
-        const float4 c2 = *reinterpret_cast<const float4 *>(a.ws.q_c2 + rb);
+        float4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, c1 = mu, c2 = mu;
+        if (LN) {
+            mu = *reinterpret_cast<const float4 *>(a.ws.q_mu1 + rb);
+            rs = *reinterpret_cast<const float4 *>(a.ws.q_rstd1 + rb);
+            c1 = *reinterpret_cast<const float4 *>(a.ws.q_c1 + rb);
+            c2 = *reinterpret_cast<const float4 *>(a.ws.q_c2 + rb);
+        }
         float ev[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ev[r] = a.ws.e_cur[(int64_t)(b0 + 4 * g + r) * E_DIM + n];
         f32x4 adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NHT / 2; ++q) {
             adx = mfma16(ad[2 * q].x, w1f[8 * q + 0], adx);
             adx2 = mfma16(ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
             adx = mfma16(ad[2 * q].y, w1f[8 * q + 1], adx);
@@ -276,18 +307,18 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
         float xv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float xhat = (ev[r] - muv[r]) * rsv[r];
-            xv[r] = xhat * g1 + be1;
+            const float xhat = LN ? (ev[r] - muv[r]) * rsv[r] : ev[r];
+            xv[r] = LN ? xhat * g1 + be1 : ev[r];
             const float dX = adx[r] + adx2[r];
             s_dg += dX * xhat;
             s_db += dX;
-            const float dh0 = rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM)));
+            const float dh0 = LN ? rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM))) : dX;
             de_h[(int64_t)(b0 + 4 * g + r) * E_DIM + n] = dh0;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < NHT; ++mt)
                 accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
         }
     }
@@ -296,28 +327,29 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     {
         float *mine = red + (w * QB_ACC) * 64 + lane;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < NHT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[(mt * 4 + r) * 64] = accW1[mt][r];
         s_dg += __shfl_xor(s_dg, 16, 64);
         s_dg += __shfl_xor(s_dg, 32, 64);
         s_db += __shfl_xor(s_db, 16, 64);
         s_db += __shfl_xor(s_db, 32, 64);
-        mine[32 * 64] = s_dg;
-        mine[33 * 64] = s_db;
+        mine[(4 * NHT) * 64] = s_dg;
+        mine[(4 * NHT + 1) * 64] = s_db;
     }
     __syncthreads();
-    float *slab = a.ws.q_slabs + (int64_t)hd * Q_SLAB;
+    float *slab = a.ws.q_slabs + (int64_t)hd * a.q_slab;
+    constexpr int W1_OFF = LN ? 2 * E_DIM : 0;
     for (int idx = tid; idx < QB_ACC * 64; idx += 256) {
         const int slot = idx >> 6, l = idx & 63;
         const float v = ((red[(0 * QB_ACC + slot) * 64 + l] + red[(1 * QB_ACC + slot) * 64 + l]) +
                          red[(2 * QB_ACC + slot) * 64 + l]) + red[(3 * QB_ACC + slot) * 64 + l];
         const int lj = l & 15, lg = l >> 4;
-        if (slot < 32) {
+        if (slot < 4 * NHT) {
             const int mt = slot >> 2, r = slot & 3;        // row hh = 16*mt + 4*lg + r, col n = cs*16 + lj
-            slab[2 * E_DIM + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
-        } else if (lg == 0) {
-            if (slot == 32) slab[cs * 16 + lj] = v;            // d ln1_g
+            slab[W1_OFF + (int64_t)(16 * mt + 4 * lg + r) * E_DIM + cs * 16 + lj] = v;
+        } else if (LN && lg == 0) {
+            if (slot == 4 * NHT) slab[cs * 16 + lj] = v;       // d ln1_g
             else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
         }
     }
@@ -326,12 +358,12 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
 // ---- post-kernel roles ---------------------------------------------------------------------------
 // slab sum of the Q heads: float4 index i over [heads][Q_SLAB/4]; adds the Theil term kappa_h * theta
 __device__ __forceinline__ void q_slab_sum(const IqnArgs &a, int64_t i, const float *kappa, float &sq) {
-    const int per_head = Q_SLAB / 4;
+    const int per_head = a.q_slab / 4;
     const int hd = (int)(i / per_head);
     const int64_t o = (i - (int64_t)hd * per_head) * 4;
-    float4 s = *reinterpret_cast<const float4 *>(a.ws.q_slabs + (int64_t)hd * Q_SLAB + o);
-    // parameter order inside a head: ln1_g | ln1_b | w1 (contiguous), the slab has the same order
-    const int64_t po = a.off.head_base + (int64_t)hd * a.off.head_stride + a.off.h_ln1_g + o;
+    float4 s = *reinterpret_cast<const float4 *>(a.ws.q_slabs + (int64_t)hd * a.q_slab + o);
+    // parameter order inside a head: [ln1_g | ln1_b |] w1 (contiguous), the slab has the same order
+    const int64_t po = a.off.head_base + (int64_t)hd * a.off.head_stride + (a.ln ? a.off.h_ln1_g : a.off.h_w1) + o;
     if (kappa) {
         const float4 th = ld4u(a.params + po);
         const float k = kappa[hd];
@@ -342,19 +374,21 @@ __device__ __forceinline__ void q_slab_sum(const IqnArgs &a, int64_t i, const fl
     sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
 }
 
-// b1, LN2 affine, W2, b2 gradients of head `hd` for the 64 hidden units [slice*64, +64).  1024 threads.
+// b1, LN2 affine, W2, b2 gradients of head `hd` for the 16 hidden units [slice*16, +16).  1024 threads.
 __device__ __forceinline__ void q_small_tensor_block(const IqnArgs &a, int hd, int slice, const float *kappa, float &sq,
                                                      float *pool) {
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
     float *Gh = a.grads + a.off.head_base + (int64_t)hd * a.off.head_stride;
-    SmallIo io{Ph + a.off.h_w2, Ph + a.off.h_ln2_g, Ph + a.off.h_ln2_b, Ph + a.off.h_b1, Ph + a.off.h_b2,
-               Gh + a.off.h_w2, Gh + a.off.h_ln2_g, Gh + a.off.h_ln2_b, Gh + a.off.h_b1, Gh + a.off.h_b2,
-               kappa ? kappa[hd] : 0.f, kappa != nullptr, nullptr, H_DIM};
+    const bool ln = a.ln != 0;
+    const int H = a.Hq;
+    SmallIo io{Ph + a.off.h_w2, ln ? Ph + a.off.h_ln2_g : nullptr, ln ? Ph + a.off.h_ln2_b : nullptr, Ph + a.off.h_b1, Ph + a.off.h_b2,
+               Gh + a.off.h_w2, ln ? Gh + a.off.h_ln2_g : nullptr, ln ? Gh + a.off.h_ln2_b : nullptr, Gh + a.off.h_b1, Gh + a.off.h_b2,
+               kappa ? kappa[hd] : 0.f, kappa != nullptr, nullptr, H};
     const int64_t r0 = (int64_t)hd * a.B;
     small_fold_block(a, slice, sq, pool, io,
                      [&](int b, int h, bool) {
                          const float dq = a.ws.q_dq[r0 + b];
-                         return make_float3(dq * a.ws.q_xhat2[(r0 + b) * H_DIM + h], a.ws.q_dpre1[(r0 + b) * H_DIM + h], dq);
+                         return make_float3(dq * a.ws.q_xhat2[(r0 + b) * H + h], a.ws.q_dpre1[(r0 + b) * H + h], dq);
                      },
                      nullptr);
 }

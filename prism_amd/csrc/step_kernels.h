@@ -12,57 +12,58 @@ namespace prism {
 
 
 // ---- the parameter-only roles that ride along with the embed / front launch ---------------------
-// IQN: u,v (H/4 blocks), weight packing (PACK_BLOCKS, x2 with a target network);
-// Q heads: per head W1 packing (x2 with target), u_h,v_h (H/4 blocks), ||theta_h||^2 (1 block).
-__host__ __device__ inline int front_extra_blocks(int use_iqn, int n_heads, int has_target, int head_layers = 2) {
+// IQN: per weight set (online, target) u,v (H/4 blocks, LayerNorm only) and the stream-packed weights;
+// Q heads: per head and weight set W1 packing and u_h,v_h; per head ||theta_h||^2 (online).
+struct ExtraDims {
+    int use_iqn, n_heads, has_target, head_layers, Hi, Hq, ln;
+};
+__host__ __device__ inline ExtraDims extra_dims(const IqnArgs &a) {
+    return ExtraDims{a.use_iqn, a.n_heads, a.has_target, a.head_layers, a.Hi, a.Hq, a.ln};
+}
+__host__ __device__ inline int front_extra_blocks(const ExtraDims &d) {
+    const int sets = 1 + (d.has_target ? 1 : 0);
+    const int heads = d.head_layers == 1 ? 0 : d.n_heads;        // single-Linear DQN head: nothing to pack or precompute
     int n = 0;
-    if (head_layers == 1) n_heads = 0;        // single-Linear DQN head: nothing to pack or precompute
-    if (use_iqn) n += H_DIM / 4 + PACK_BLOCKS * (1 + (has_target ? 1 : 0));
-    n += n_heads * (Q_PACK_BLOCKS_PER_HEAD * (1 + (has_target ? 1 : 0)) + H_DIM / 4 + Q_NORM_PARTS);
+    if (d.use_iqn) n += sets * ((d.ln ? d.Hi / 4 : 0) + iqn_pack_blocks(d.Hi));
+    n += heads * (sets * (q_pack_blocks_per_head(d.Hq) + (d.ln ? d.Hq / 4 : 0)) + Q_NORM_PARTS);
     return n;
 }
 
 __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float *s_red) {
     const int tid = threadIdx.x;
+    const int sets = 1 + (a.has_target ? 1 : 0);
     if (a.use_iqn) {
-        if (x < H_DIM / 4) {
-            iqn_uv_block(a, x * 4 + (tid >> 6), tid & 63);
-            return;
-        }
-        x -= H_DIM / 4;
-        if (x < PACK_BLOCKS) {
-            pack_weights_block(a.params, a.off, a.ws.wpk[0], x, tid);
-            return;
-        }
-        x -= PACK_BLOCKS;
-        if (a.has_target) {
-            if (x < PACK_BLOCKS) {
-                pack_weights_block(a.target_params, a.off, a.ws.wpk[1], x, tid);
+        const int nuv = a.ln ? a.Hi / 4 : 0, npk = iqn_pack_blocks(a.Hi);
+        for (int set = 0; set < sets; ++set) {
+            if (x < nuv) {
+                iqn_uv_block(a, set, x * 4 + (tid >> 6), tid & 63);
                 return;
             }
-            x -= PACK_BLOCKS;
+            x -= nuv;
+            if (x < npk) {
+                pack_weights_block(set ? a.target_params : a.params, a.off, a.Hi, a.ln, a.ws.wpk[set], x, tid);
+                return;
+            }
+            x -= npk;
         }
     }
-    const int per_head = Q_PACK_BLOCKS_PER_HEAD * (1 + (a.has_target ? 1 : 0)) + H_DIM / 4 + Q_NORM_PARTS;
+    const int nuv = a.ln ? a.Hq / 4 : 0, npk = q_pack_blocks_per_head(a.Hq);
+    const int per_head = sets * (npk + nuv) + Q_NORM_PARTS;
     const int hd = x / per_head;
     x -= hd * per_head;
-    if (x < Q_PACK_BLOCKS_PER_HEAD) {
-        pack_head_w1_block(a.params, a.off, a.ws.q_wpk[0], hd, x, tid);
-        return;
-    }
-    x -= Q_PACK_BLOCKS_PER_HEAD;
-    if (a.has_target) {
-        if (x < Q_PACK_BLOCKS_PER_HEAD) {
-            pack_head_w1_block(a.target_params, a.off, a.ws.q_wpk[1], hd, x, tid);
+    for (int set = 0; set < sets; ++set) {
+        if (x < npk) {
+            pack_head_w1_block(set ? a.target_params : a.params, a.off, a.Hq, a.ln, a.ws.q_wpk[set], hd, x, tid);
             return;
         }
-        x -= Q_PACK_BLOCKS_PER_HEAD;
+        x -= npk;
+        if (x < nuv) {
+            q_uv_block(a, set, hd, x * 4 + (tid >> 6), tid & 63);
+            return;
+        }
+        x -= nuv;
     }
-    if (x < H_DIM / 4) {
-        q_uv_block(a, hd, x * 4 + (tid >> 6), tid & 63);
-        return;
-    }
-    q_head_norm_block(a, hd, x - H_DIM / 4, s_red);
+    q_head_norm_block(a, hd, x, s_red);
 }
 
 __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red) { front_extra_block(a, x, s_red); }
@@ -248,15 +249,14 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
 //   [.., + POST_SMALL_BLOCKS)             small tensors (b1, LN2, W2, b2) by 64-wide slices of H, + total loss
 // Every block leaves its sum of squares in normpart[blockIdx.x].
 // ------------------------------------------------------------------------------------------
-constexpr int POST_SLAB_BLOCKS = (SLAB / 4 + 1023) / 1024;   // 49
-constexpr int POST_SMALL_BLOCKS = H_DIM / SMALL_W;           // 8 (IQN small tensors, 16 hidden units per block)
-constexpr int POST_QSMALL_BLOCKS = H_DIM / SMALL_W;          // 8 per head (16 hidden units per block)
-
-__host__ __device__ inline int post_q_slab_blocks(int n_heads) { return (n_heads * (Q_SLAB / 4) + 1023) / 1024; }
-__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd) {
+__host__ __device__ inline int post_slab_blocks(int slab) { return (slab / 4 + 1023) / 1024; }
+__host__ __device__ inline int post_small_blocks(int H) { return H / SMALL_W; }     // 16 hidden units per block
+__host__ __device__ inline int post_q_slab_blocks(int n_heads, int q_slab) { return (n_heads * (q_slab / 4) + 1023) / 1024; }
+__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd, int slab, int q_slab, int Hi,
+                                           int Hq) {
     int n = conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
-    if (use_iqn) n += POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
-    if (n_heads) n += post_q_slab_blocks(n_heads) + n_heads * POST_QSMALL_BLOCKS;
+    if (use_iqn) n += post_slab_blocks(slab) + post_small_blocks(Hi);
+    if (n_heads) n += post_q_slab_blocks(n_heads, q_slab) + n_heads * post_small_blocks(Hq);
     return n;
 }
 // one-layer DQN head: the loss kernel leaves one conv partial row per sample; CONV_FOLD_W outputs per fold block
@@ -401,14 +401,15 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         blk -= n_conv;
         bool done = false;
         if (a.use_iqn) {
-            if (blk < POST_SLAB_BLOCKS) {
+            const int n_slab = post_slab_blocks(a.slab), n_small = post_small_blocks(a.Hi);
+            if (blk < n_slab) {
                 const int i = blk * 1024 + tid;
-                if (i < SLAB / 4) {
+                if (i < a.slab / 4) {
                     float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
                     float4 v[7];
 #pragma unroll
                     for (int c = 1; c < 8; ++c)
-                        if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * SLAB)[i];
+                        if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * a.slab)[i];
 #pragma unroll
                     for (int c = 1; c < 8; ++c)
                         if (c < a.n_chunks) {
@@ -418,11 +419,11 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                     sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
                 }
                 done = true;
-            } else if (blk < POST_SLAB_BLOCKS + POST_SMALL_BLOCKS) {
-                small_tensor_block(a, blk - POST_SLAB_BLOCKS, sq, reinterpret_cast<float *>(s_pool));
+            } else if (blk < n_slab + n_small) {
+                small_tensor_block(a, blk - n_slab, sq, reinterpret_cast<float *>(s_pool));
                 done = true;
             } else {
-                blk -= POST_SLAB_BLOCKS + POST_SMALL_BLOCKS;
+                blk -= n_slab + n_small;
             }
         }
         if (!done && a.head_layers == 1) {
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 __syncthreads();
                 kappa = s_kappa;
             }
-            const int nqs = post_q_slab_blocks(a.n_heads);
+            const int nqs = post_q_slab_blocks(a.n_heads, a.q_slab), nqsm = post_small_blocks(a.Hq);
             if (blk < nqs) {
                 const int64_t i = (int64_t)blk * 1024 + tid;
-                if (i < (int64_t)a.n_heads * (Q_SLAB / 4)) q_slab_sum(a, i, kappa, sq);
+                if (i < (int64_t)a.n_heads * (a.q_slab / 4)) q_slab_sum(a, i, kappa, sq);
             } else {
                 const int x = blk - nqs;
                 // total loss (agent.py:58-64): mean(dl*w) + mean(ql*w); operands requested before the fold
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                         if (a.use_iqn) li += a.ws.lossw[b];
                     }
                 }
-                q_small_tensor_block(a, x / POST_QSMALL_BLOCKS, x % POST_QSMALL_BLOCKS, kappa, sq,
+                q_small_tensor_block(a, x / nqsm, x % nqsm, kappa, sq,
                                      reinterpret_cast<float *>(s_pool));
                 if (x == 0) {
                     const float tq = block_sum_1024(lw, s_red);

@@ -129,7 +129,7 @@ def test_philox_taus_are_uniform_and_recorded(dev):
 def test_unsupported_config_fails_loudly(dev):
     from prism_amd.factory.model_factory import UnsupportedConfig
     g = H.load_case("iqn_c3")
-    cfg, agent = build_hip_agent(g, dev, use_layer_norm=False)
+    cfg, agent = build_hip_agent(g, dev, iqn_quantile_model_feature_dim=512)     # widths covered: 128, 256
     batch, w, taus = H.case_batch(g, 0)
     with pytest.raises(UnsupportedConfig):
         agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev))
