@@ -54,7 +54,7 @@ class ModelSpec:
 
 def conv_embed(p, obs):
     """(B,10,10,C) -> (B,1024), channel-major flatten."""
-    x = obs.permute(0, 3, 1, 2).float()
+    x = obs.permute(0, 3, 1, 2).to(p["embedding_model.model.0.weight"].dtype)      # (.float() in the reference)
     y = F.relu(F.conv2d(x, p["embedding_model.model.0.weight"], p["embedding_model.model.0.bias"]))
     return y.flatten(1)
 
@@ -215,6 +215,23 @@ class LearnerOracle:
         self.opt = torch.optim.Adam(list(self.p.values()), lr=spec.lr, betas=(spec.beta1, spec.beta2),
                                     eps=spec.adam_eps)
         self.last = {}
+
+    def grads_fp64(self, batch, per_weights, taus):
+        """The same gradient evaluated in float64 at the current (fp32) parameters.  Where a ReLU input sits
+        within fp32 rounding distance of zero, the fp32 autograd result and this one differ by that unit's
+        whole contribution; a correct fp32 kernel may land on either side (tests accept both)."""
+        p64 = {k: v.detach().double().requires_grad_(True) for k, v in self.p.items()}
+        pt64 = None if self.p_tgt is None else {k: v.double() for k, v in self.p_tgt.items()}
+        b64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        dl, ql, _, _ = composite_losses(p64, pt64, self.spec, b64, [t.double() for t in taus])
+        w = per_weights.double() if torch.is_tensor(per_weights) else per_weights
+        total = 0
+        if dl is not None:
+            total = total + (dl * w).mean()
+        if ql is not None:
+            total = total + (ql * w).mean()
+        total.backward()
+        return {k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in p64.items()}
 
     def update(self, batch, per_weights, taus, apply=True):
         dl, ql, td, aux = composite_losses(self.p, self.p_tgt, self.spec, batch, taus)

@@ -79,7 +79,10 @@ class IQNHead(nn.Module):
             self.embedding_to_quantile_layer = nn.Sequential(nn.LayerNorm(n_in),
                                                              nn.Linear(n_in, n_actions)).to(device)
         else:
-            self.embedding_to_quantile_layer = nn.Linear(n_in, n_actions, device=device)
+            # (the reference passes device= to the constructor here, iqn_model.py:46, so on a GPU it draws this one
+            # layer's initial weights from the CUDA generator; created on the host like every other layer, the
+            # initial state is the same on any device and equals the reference's CPU run seed for seed)
+            self.embedding_to_quantile_layer = nn.Linear(n_in, n_actions).to(device)
 
     @torch.no_grad()
     def forward(self, e, n_quantile_samples=None, for_action=False):

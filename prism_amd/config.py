@@ -134,6 +134,26 @@ DEFAULT_CONFIG = Config(**{name: d for name, _t, d, _m in _FIELDS})
 MINATAR_CONFIG = Config(**{name: (d if m is ... else m) for name, _t, d, m in _FIELDS})
 
 
+# The two ablation presets the reference's MinAtar experiments start from
+# (prism/config/additive_ablation_base_config.py:2-52, subtractive_ablation_base_config.py:2-52), as the
+# fields that differ from DEFAULT_CONFIG.  The one-element tuples are the reference's own values (a trailing
+# comma after the string there); every consumer treats them as "none" / no clipping.
+_ABLATION_COMMON = dict(
+    embedding_model_type="minatar_cnn", atari_sticky_actions_prob=0.1, evaluation_timestep_horizon=100_000,
+    timesteps_per_report=50_000, timestep_limit=3_000_000, experience_replay_capacity=3_000_000,
+    learning_rate=0.0001, batch_size=64, num_initial_random_timesteps=4_000, frame_stack_size=1,
+    adam_epsilon=0.0003125, loss_squish_fn_id=("none",), reward_clipping_type=("dopamine clamp",),
+    log_to_wandb=True, iqn_n_current_state_quantile_samples=32, iqn_n_next_state_quantile_samples=32,
+    iqn_quantile_samples_per_action=32, iqn_quantile_model_feature_dim=256)
+_ADDITIVE = dict(
+    _ABLATION_COMMON, use_ids=False, use_layer_norm=False, dqn_n_model_feature_dim=256, dqn_n_model_layers=2,
+    use_target_network=True, use_e_greedy=True, e_greedy_decay_timesteps=250_000, n_step_returns_length=1,
+    target_update_period=4_000, num_processes=1, wandb_group_name="Second Prism Additive Ablation Experiment")
+_SUBTRACTIVE = dict(
+    _ABLATION_COMMON, ids_q_head_feature_dim=256, use_per=True, num_processes=16,
+    wandb_group_name="Prism Subtractive Ablation Experiment")
+
+
 def derive(base, **overrides):
     """``Config(**base.__dict__)`` + attribute assignment, the reference's preset idiom
     (minatar_config.py:3, additive_ablation_experiment.py:36).  Unknown names become plain
@@ -146,6 +166,10 @@ def derive(base, **overrides):
     for k, v in overrides.items():
         setattr(cfg, k, v)
     return cfg
+
+
+ADDITIVE_ABLATION_BASE_CONFIG = derive(DEFAULT_CONFIG, **_ADDITIVE)
+SUBTRACTIVE_ABLATION_BASE_CONFIG = derive(DEFAULT_CONFIG, **_SUBTRACTIVE)
 
 
 def baseline_config(i, **overrides):

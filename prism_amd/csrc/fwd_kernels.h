@@ -465,9 +465,15 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
         const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
         const float kap = a.huber_k;
         float mean = 0.f;
-        if (lane < A) {
+        {
+            // (T <= 8 here: all reads issue together, then the adds run in the sequential order)
+            float zv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zv[j] = zt[(rb + T + (j < T ? j : 0)) * FW_ZS + (lane < A ? lane : 0)];
             float sacc = 0.f;
-            for (int j = 0; j < T; ++j) sacc += zt[(rb + T + j) * FW_ZS + lane];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < T) sacc += zv[j];
             mean = sacc / (float)T;
         }
         int astar = 0;
@@ -568,8 +574,12 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
     for (int o = tid; o < ns * 2 * H; o += 512) {
         const int smp = o / (2 * H), k = o - smp * 2 * H, which = k >= H, h = which ? k - H : k;
         const float *src = (which ? sP : sS) + (smp * 2 * T) * HP + h;
-        float t = 0.f;
-        for (int tt = 0; tt < T; ++tt) t += src[tt * HP];
+        float tv[8], t = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) tv[tt] = src[(tt < T ? tt : 0) * HP];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+            if (tt < T) t += tv[tt];
         (which ? a.ws.Pb : a.ws.Sb)[(int64_t)(tile * ns + smp) * H + h] = t;
     }
     if (tid < ns) {

@@ -237,9 +237,14 @@ __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
 // (a plain __syncthreads() also waits for vmcnt(0), which would serialise every weight prefetch).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// shader-clock stamps (s_memtime: per-XCD counters, only differences inside one workgroup mean anything) plus,
+// in slots 60.. the chip-wide 100 MHz real-time counter of the same moments (for spans across workgroups)
 #define PRISM_STAMP(k)                                                                     \
     do {                                                                                   \
-        if ((a.dbg & 8) && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if ((a.dbg & 8) && threadIdx.x == 0) {                                             \
+            a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();        \
+            a.stamps[(size_t)blockIdx.x * 64 + 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                  \
     } while (0)
 
 constexpr int LOSS_WAVES = 8;
@@ -422,11 +427,21 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// bwd: grid = (E/16 column slices) x n_chunks row chunks, 256 threads = 4 waves.
-// Each wave walks a contiguous run of 16-row tiles; everything a tile needs comes straight from
-// global/L2 into registers, LDS only transposes the two operands that are needed k-major.
+// bwd: grid = (E/16 column slices) x n_chunks row chunks, 256 threads = 4 waves; each wave walks a contiguous
+// run of 16-row tiles.  Per tile and wave, four products on the fp32 MFMA (16x16x4):
+//   phi[m][n]   = cos[m][:] . Wphi[n][:]           (recomputed; A = cos rows,   B = Wphi slice)
+//   dX[m][n]    = dpre1[m][:] . W1[:][n]           (A = dpre1 rows, B = W1 slice)
+//   dWphi[n][k] += dphi[m][n] cos[m][k]            (A = dphi: the D registers of the elementwise step, B = cos)
+//   dW1[h][n]   += dpre1[m][h] x[m][n]             (A = dpre1, B = x: D registers again)
+// The two row operands (cos, dpre1) are needed once with the row on the lane (first pair) and once with the
+// row on the k index (second pair).  Both forms are loaded straight from global memory as whole-row 16-byte
+// pieces -- the second form assigns the basis / hidden index to (lane, register) as {4 j + c}, a permutation
+// that only changes where each accumulator element is written at the end -- so no LDS transpose, no LDS
+// traffic in the loop except the workgroup's fixed weight slices (parked there once).  Every register set is
+// refilled for the NEXT tile right after its last use (rolling prefetch, no extra registers), and the
+// instruction order is pinned: the elementwise step of row group r+1 runs in the shadow of the MFMAs of
+// row group r.
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int bwd_wave_lds(int H) { return 16 * CS + 16 * (H + 4); }   // floats per wave (cos tile + dpre1 tile)
 __host__ __device__ constexpr int bwd_acc(int H) { return 16 + H / 4 + 3; }                 // accumulators reduced across waves
 // conv-backward partials ride along in the tile loop (IQN-only models: d e[b][n] is final per
 // (sample, column) right there).  The lanes that hold one (sample, position) value -- `share` of
@@ -434,8 +449,9 @@ __host__ __device__ constexpr int bwd_acc(int H) { return 16 + H / 4 + 3; }     
 // of C/share channels in registers.
 constexpr int BWD_CONV_TAPS = 18;                   // taps per lane: 9 * C / share
 constexpr int BWD_CONV_ROW = 96;                    // floats per partial row: 9C taps (C <= 10) + bias
+__host__ __device__ constexpr int bwd_w_lds(int H) { return 16 * K_BASIS + 16 * H; }        // Wphi slice | W1 slice, operand order
 __host__ __device__ constexpr int bwd_main_lds(int H) {
-    return 4 * bwd_acc(H) * 64 > 4 * bwd_wave_lds(H) ? 4 * bwd_acc(H) * 64 : 4 * bwd_wave_lds(H);
+    return 4 * bwd_acc(H) * 64 > bwd_w_lds(H) ? 4 * bwd_acc(H) * 64 : bwd_w_lds(H);
 }
 constexpr int BWD_CONV_PRE4 = 12;                   // float4 registers per lane staging the wave's observation rows
 __host__ __device__ inline int bwd_conv_share(int T) { return T == 4 ? 1 : (T == 8 ? 2 : 4); }
@@ -458,8 +474,10 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
 
 template <int H, bool LN>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
-    constexpr int NHT = H / 16, HS = H + 4, BWD_WAVE_LDS = bwd_wave_lds(H), BWD_ACC = bwd_acc(H), BWD_MAIN_LDS = bwd_main_lds(H);
+    constexpr int NHT = H / 16, NU = H / 64, BWD_ACC = bwd_acc(H), BWD_MAIN_LDS = bwd_main_lds(H);
     constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);     // slab: phi_w | phi_b | [ln1_g | ln1_b] | w1
+    typedef const f32x4 __attribute__((address_space(1))) *g4;
+    typedef const float __attribute__((address_space(1))) *g1p;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
@@ -471,11 +489,29 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     const int unit = T > 16 ? T / 16 : 1;
     const int units_total = (R / 16) / unit;
     const int gw = rc * 4 + w, nw = a.n_chunks * 4;
-    const int tile_begin = (int)(((int64_t)units_total * gw) / nw) * unit;
-    const int tiles_per_wave = (int)(((int64_t)units_total * (gw + 1)) / nw) * unit - tile_begin;
-    float *cosl = smem + w * BWD_WAVE_LDS;
-    float *dpl = cosl + 16 * CS;
-    const float *P = a.params;
+    // (wave-uniform by construction; made provably so, so that tile offsets live in scalar registers)
+    const int tile_begin = __builtin_amdgcn_readfirstlane((int)(((int64_t)units_total * gw) / nw) * unit);
+    const int tiles_per_wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)units_total * (gw + 1)) / nw) * unit) - tile_begin;
+    const g1p P = (g1p)a.params;
+    const g1p e_cur = (g1p)a.ws.e_cur;
+    // the row operands are read through buffer descriptors: one loop-invariant 32-bit lane offset per stream,
+    // the tile offset in a scalar register, everything else in the instruction's immediate
+    const __amdgpu_buffer_rsrc_t rs_cos = __builtin_amdgcn_make_buffer_rsrc(a.ws.cosb, 0, R * K_BASIS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dp = __builtin_amdgcn_make_buffer_rsrc(a.ws.dpre1, 0, R * H * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mu = __builtin_amdgcn_make_buffer_rsrc(a.ws.mu1, 0, R * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rs = __builtin_amdgcn_make_buffer_rsrc(a.ws.rstd1, 0, R * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c1 = __builtin_amdgcn_make_buffer_rsrc(a.ws.c1, 0, R * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c2 = __builtin_amdgcn_make_buffer_rsrc(a.ws.c2, 0, R * 4, 0x00020000);
+    auto bload4 = [](__amdgpu_buffer_rsrc_t rs, int voff, int soff) __attribute__((always_inline)) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
+    const int vo_ca = (j * K_BASIS + 4 * g) * 4, vo_da = (j * H + 4 * g) * 4;          // row on the lane
+    const int vo_cb = (4 * g * K_BASIS + 4 * j) * 4, vo_db = (4 * g * H + 4 * j) * 4;  // row on the k index
+    const int vo_sc = 4 * g * 4;
+    f32x4 *wphil = reinterpret_cast<f32x4 *>(smem);             // [q][lane]: Wphi[n][16q + 4g + jj]
+    f32x4 *w1l = wphil + 4 * 64;                                // [q][lane]: W1[h = 16q + 4g + jj][n]
     // conv-backward taps of this lane: channels [sub * cpl, (sub + 1) * cpl) x 3 x 3
     const int C = a.C, y0 = (cs & 3) * 2;
     const int share = bwd_conv_share(T), cpl = C / share, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
@@ -483,127 +519,146 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     float cacc[BWD_CONV_TAPS], cbias = 0.f;
 #pragma unroll
     for (int i = 0; i < BWD_CONV_TAPS; ++i) cacc[i] = 0.f;
-    // observation rows y0..y0+3 of this wave's samples: requested first thing, parked in LDS (per
-    // wave, no block barrier) right before the tile loop
+    // observation rows y0..y0+3 of this wave's samples: requested first thing, straight into LDS (LDS-DMA: 16 B
+    // per lane, lane-linear destination, no registers); the barrier in front of the tile loop covers them
     const int ws_lo = (tile_begin * 16) / T, ws_n = n_mine ? (tiles_per_wave * 16) / T : 0;
     float *s_obs = smem + BWD_MAIN_LDS + 4 * BWD_CONV_ROW + w * (bwd_conv_spw(a.B, a.n_chunks) * 40 * C);
-    float4 pre4[BWD_CONV_PRE4];
 #pragma unroll
     for (int i = 0; i < BWD_CONV_PRE4; ++i) {
-        pre4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int idx = lane + 64 * i;
         if (idx < ws_n * 10 * C) {
             const int s = idx / (10 * C), o4 = idx - s * 10 * C;
-            pre4[i] = reinterpret_cast<const float4 *>(a.obs + ((int64_t)(ws_lo + s) * 100 + y0 * 10) * C)[o4];
+            const float *src = a.obs + ((int64_t)(ws_lo + s) * 100 + y0 * 10) * C + 4 * o4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_obs + 256 * i), 16, 0, 0);
         }
     }
-
     PRISM_STAMP(8);
-    // per-lane constants ------------------------------------------------------------------------
-    float4 wphi[4];   // B operand of phi: Wphi[n][16q + 4g + jj]
+    // ---- the workgroup's weight slices -> LDS in B-operand order -------------------------------
     {
-        const float *src = P + a.off.phi_w + (int64_t)n * K_BASIS + 4 * g;
+        // Wphi rows cs*16 .. +15 are one contiguous 4 KB run: thread t takes float4 t
+        const int jj = tid >> 4, f4 = tid & 15;
+        const f32x4 v = *reinterpret_cast<g4>(P + a.off.phi_w + (int64_t)(cs * 16 + jj) * K_BASIS + 4 * f4);
+        wphil[(f4 >> 2) * 64 + (f4 & 3) * 16 + jj] = v;
+        // W1[h][cs*16 .. +15]: 64 B per row; thread takes (row h, float4 c4), scatters its 4 columns
+        float *w1f = reinterpret_cast<float *>(w1l);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wphi[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-    }
-    float w1f[4 * NHT];    // B operand of dX: W1[h = 16q + 4g + jj][n]
-    {
-        const float *src = P + a.off.iqn_w1 + n;
+        for (int i = 0; i < H / 64; ++i) {
+            const int h = (tid >> 2) + 64 * i, c4 = tid & 3;
+            const f32x4 x = *reinterpret_cast<g4>(P + a.off.iqn_w1 + (int64_t)h * E_DIM + cs * 16 + 4 * c4);
+            const int q = h >> 4, gg = (h >> 2) & 3, jh = h & 3;
 #pragma unroll
-        for (int q = 0; q < NHT; ++q)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) w1f[q * 4 + jj] = src[(int64_t)(16 * q + 4 * g + jj) * E_DIM];
+            for (int c = 0; c < 4; ++c) w1f[((q * 64 + gg * 16 + 4 * c4 + c) << 2) + jh] = x[c];
+        }
     }
     const float bphi = P[a.off.phi_b + n], g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
 
-    f32x4 accWphi[4], accW1[NHT];
+    f32x4 accWphi[4], accW1[NHT];     // accWphi[c][r']: dWphi[n = 4g + r'][k = 4j + c];  accW1[4u + c][r']: dW1[h = 16g + 4r' + 64u + c][n = j]
 #pragma unroll
     for (int i = 0; i < 4; ++i) accWphi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
 
-#pragma unroll
-    for (int i = 0; i < BWD_CONV_PRE4; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < ws_n * 10 * C) reinterpret_cast<float4 *>(s_obs)[idx] = pre4[i];
-    }
-    PRISM_STAMP(9);
-    // operands of one 16-row tile (fetching a tile ahead was tried twice and loses: the registers it
-    // costs matter more than the latency it hides with two workgroups per CU)
-    struct TileIn {
-        float4 ac[4], ad[NHT];   // A fragments: cos rows / dpre1 rows (row = r0 + j, k = 16q + 4g + jj)
-        float4 mu, rs, c1, c2;   // row scalars of the D-layout rows 4g..4g+3
-        float ev;
-        int bsm;
-    };
-    auto load_tile = [&](TileIn &t, int ti) {
+    // ---- operands of a tile ---------------------------------------------------------------------
+    f32x4 ac[4], ad[NHT];             // row on the lane:   cos[r0 + j][16q + 4g ..], dpre1[r0 + j][16q + 4g ..]
+    f32x4 cB[4], dB[4][NU];           // row on the k index: cos[r0 + 4g + r][4j ..],  dpre1[r0 + 4g + r][64u + 4j ..]
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, c1 = mu, c2 = mu;
+    float ev = 0.f;
+    auto load_rows_a = [&](int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
-        const float *src = a.ws.cosb + (int64_t)(r0 + j) * K_BASIS + 4 * g;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t.ac[q] = *reinterpret_cast<const float4 *>(src + 16 * q);
-        const float *sd = a.ws.dpre1 + (int64_t)(r0 + j) * H + 4 * g;
+        for (int q = 0; q < 4; ++q) ac[q] = bload4(rs_cos, vo_ca + 64 * q, r0 * K_BASIS * 4);
 #pragma unroll
-        for (int q = 0; q < NHT; ++q) t.ad[q] = *reinterpret_cast<const float4 *>(sd + 16 * q);
-        const int rb = r0 + 4 * g;
-        t.bsm = rb / T;
-        if (LN) {
-            t.mu = *reinterpret_cast<const float4 *>(a.ws.mu1 + rb);
-            t.rs = *reinterpret_cast<const float4 *>(a.ws.rstd1 + rb);
-            t.c1 = *reinterpret_cast<const float4 *>(a.ws.c1 + rb);
-            t.c2 = *reinterpret_cast<const float4 *>(a.ws.c2 + rb);
-        } else {
-            t.mu = t.c1 = t.c2 = float4{0.f, 0.f, 0.f, 0.f};
-            t.rs = float4{1.f, 1.f, 1.f, 1.f};
-        }
-        t.ev = a.ws.e_cur[(int64_t)t.bsm * E_DIM + n];
+        for (int q = 0; q < NHT; ++q) ad[q] = bload4(rs_dp, vo_da + 64 * q, r0 * H * 4);
     };
-    auto process_tile = [&](const TileIn &t, int ti) {
+    auto load_rows_b = [&](int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
-        // stage both tiles in LDS for the k-major reads of the weight-gradient products
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&cosl[j * CS + 16 * q + 4 * g]) = t.ac[q];
-#pragma unroll
-        for (int q = 0; q < NHT; ++q) *reinterpret_cast<float4 *>(&dpl[j * HS + 16 * q + 4 * g]) = t.ad[q];
-        const int bsm = t.bsm;
-        const float ev = t.ev;
-        // phi columns and dX columns: three independent MFMA chains interleaved
-        f32x4 aphi = {0.f, 0.f, 0.f, 0.f}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < NHT / 2; ++q) {
-            if (q < 4) aphi = mfma16(t.ac[q & 3].x, wphi[q & 3].x, aphi);
-            adx = mfma16(t.ad[2 * q].x, w1f[8 * q + 0], adx);
-            adx2 = mfma16(t.ad[2 * q + 1].x, w1f[8 * q + 4], adx2);
-            if (q < 4) aphi = mfma16(t.ac[q & 3].y, wphi[q & 3].y, aphi);
-            adx = mfma16(t.ad[2 * q].y, w1f[8 * q + 1], adx);
-            adx2 = mfma16(t.ad[2 * q + 1].y, w1f[8 * q + 5], adx2);
-            if (q < 4) aphi = mfma16(t.ac[q & 3].z, wphi[q & 3].z, aphi);
-            adx = mfma16(t.ad[2 * q].z, w1f[8 * q + 2], adx);
-            adx2 = mfma16(t.ad[2 * q + 1].z, w1f[8 * q + 6], adx2);
-            if (q < 4) aphi = mfma16(t.ac[q & 3].w, wphi[q & 3].w, aphi);
-            adx = mfma16(t.ad[2 * q].w, w1f[8 * q + 3], adx);
-            adx2 = mfma16(t.ad[2 * q + 1].w, w1f[8 * q + 7], adx2);
-        }
-        // elementwise backward on the 4 rows this lane holds (column n)
-        const float muv[4] = {t.mu.x, t.mu.y, t.mu.z, t.mu.w}, rsv[4] = {t.rs.x, t.rs.y, t.rs.z, t.rs.w};
-        const float c1v[4] = {t.c1.x, t.c1.y, t.c1.z, t.c1.w}, c2v[4] = {t.c2.x, t.c2.y, t.c2.z, t.c2.w};
-        float xv[4], dpp[4];
-        float dep = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float phi = fmaxf(aphi[r] + bphi, 0.f);
+            cB[r] = bload4(rs_cos, vo_cb + r * K_BASIS * 4, r0 * K_BASIS * 4);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) dB[r][u] = bload4(rs_dp, vo_db + r * H * 4 + 256 * u, r0 * H * 4);
+        }
+    };
+    auto load_scalars = [&](int ti) __attribute__((always_inline)) {
+        const int r0 = (tile_begin + ti) * 16;
+        if (LN) {
+            mu = bload4(rs_mu, vo_sc, r0 * 4);
+            rs = bload4(rs_rs, vo_sc, r0 * 4);
+            c1 = bload4(rs_c1, vo_sc, r0 * 4);
+            c2 = bload4(rs_c2, vo_sc, r0 * 4);
+        }
+        ev = e_cur[(int64_t)((r0 + 4 * g) / T) * E_DIM + n];
+    };
+    if (tiles_per_wave > 0) {
+        load_rows_a(0);
+        load_scalars(0);
+        load_rows_b(0);
+    }
+    __syncthreads();          // weight slices (and every wave's observation rows) are in LDS
+    PRISM_STAMP(9);
+
+    for (int ti = 0; ti < tiles_per_wave; ++ti) {
+        const int r0 = (tile_begin + ti) * 16;
+        const bool more = ti + 1 < tiles_per_wave;
+        const int bsm = (r0 + 4 * g) / T;
+        // ---- phi columns and dX columns: three independent MFMA chains interleaved -------------------
+        f32x4 aphi = {bphi, bphi, bphi, bphi}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NHT / 2; ++q) {
+            const f32x4 wa = w1l[(2 * q) * 64 + lane], wb = w1l[(2 * q + 1) * 64 + lane];
+            f32x4 wp = {0.f, 0.f, 0.f, 0.f};
+            if (q < 4) wp = wphil[(q & 3) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (q < 4) aphi = mfma16(ac[q & 3][c], wp[c], aphi);
+                adx = mfma16(ad[2 * q][c], wa[c], adx);
+                adx2 = mfma16(ad[2 * q + 1][c], wb[c], adx2);
+            }
+            if (q & 1) __builtin_amdgcn_sched_barrier(0);      // (bounds how many weight registers are in flight)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_rows_a(ti + 1);            // the row-on-lane registers are free: refill them for the next tile
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- elementwise backward of row group r (column n), then the weight-gradient MFMAs of that group:
+        // the VALU work of group r + 1 issues in the shadow of the MFMAs of group r
+        float dep = 0.f;
+        float xv = 0.f, dpp = 0.f;
+        auto elementwise = [&](int r) __attribute__((always_inline)) {
+            const float phi = fmaxf(aphi[r], 0.f);          // (bias already in the accumulator)
             const float h0 = phi * ev;
-            const float xhat = LN ? (h0 - muv[r]) * rsv[r] : h0;
-            xv[r] = LN ? xhat * g1 + be1 : h0;        // trunk input (B operand of dW1)
+            const float xhat = LN ? (h0 - mu[r]) * rs[r] : h0;
+            xv = LN ? xhat * g1 + be1 : h0;                 // trunk input (B operand of dW1)
             const float dX = adx[r] + adx2[r];
             s_dg += dX * xhat;
             s_db += dX;
-            const float dh0 = LN ? rsv[r] * (dX * g1 - c1v[r] * (1.0f / E_DIM) - xhat * (c2v[r] * (1.0f / E_DIM))) : dX;
+            const float dh0 = LN ? rs[r] * (dX * g1 - c1[r] * (1.0f / E_DIM) - xhat * (c2[r] * (1.0f / E_DIM))) : dX;
             dep += dh0 * phi;
-            const float dphi = (phi > 0.f) ? dh0 * ev : 0.f;
-            dpp[r] = dphi;
-            s_dbphi += dphi;
+            dpp = (phi > 0.f) ? dh0 * ev : 0.f;
+            s_dbphi += dpp;
+        };
+        elementwise(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xr = xv, dr = dpp;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accWphi[c] = mfma16(dr, cB[r][c], accWphi[c]);
+            if (r < 3) elementwise(r + 1);
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) accW1[4 * u + c] = mfma16(dB[r][u][c], xr, accW1[4 * u + c]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool ev_pos = ev > 0.f;
+        if (more) {
+            load_rows_b(ti + 1);
+            load_scalars(ti + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // d e[b][n]: sum over the T rows of a sample
         float dcv = 0.f;          // ReLU-masked d e of (sample, column n) when it is final in this lane
         if (T == 4) {
@@ -611,44 +666,18 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
         } else if (T == 8) {
             dep += __shfl_xor(dep, 16, 64);
             if (!n_mine && (g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
-            dcv = ev > 0.f ? dep : 0.f;
+            dcv = ev_pos ? dep : 0.f;
         } else {
             dep += __shfl_xor(dep, 16, 64);
             dep += __shfl_xor(dep, 32, 64);
             de_acc += dep;
             if (((r0 + 16) % T) == 0) {
                 if (!n_mine && g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
-                dcv = ev > 0.f ? de_acc : 0.f;
+                dcv = ev_pos ? de_acc : 0.f;
                 de_acc = 0.f;
             }
         }
         if (sub == 0) cbias += dcv;
-        // dWphi[n-slice][64] += dphi^T (16 cols x 16 rows) . cos (16 rows x 64)   (A = dpp: D layout == A^T layout)
-        // dW1[128][n-slice]  += dpre1^T (128 x 16 rows) . X (16 rows x 16 cols)    (B = xv)
-        // k-step outer, accumulator inner: consecutive MFMAs never touch the same accumulator
-        // The 12 LDS operands of a k-step are read as ONE batch, one k-step ahead of the MFMAs that
-        // use them (left to itself the compiler reads two values, waits, issues two MFMAs, ...: the
-        // matrix pipe then idles for an LDS round trip every other instruction).
-        float cv[2][4], dv[2][NHT];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) cv[0][kt] = cosl[(4 * g) * CS + 16 * kt + j];
-#pragma unroll
-        for (int mt = 0; mt < NHT; ++mt) dv[0][mt] = dpl[(4 * g) * HS + 16 * mt + j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (r < 3) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) cv[(r + 1) & 1][kt] = cosl[(4 * g + r + 1) * CS + 16 * kt + j];
-#pragma unroll
-                for (int mt = 0; mt < NHT; ++mt) dv[(r + 1) & 1][mt] = dpl[(4 * g + r + 1) * HS + 16 * mt + j];
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the read batch ahead of this k-step's MFMAs
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) accWphi[kt] = mfma16(dpp[r], cv[r & 1][kt], accWphi[kt]);
-#pragma unroll
-            for (int mt = 0; mt < NHT; ++mt) accW1[mt] = mfma16(dv[r & 1][mt], xv[r], accW1[mt]);
-        }
         // conv taps of (sample bsm, channel cs>>2, output position (y0 + (j>>3), j&7)); LDS reads of
         // this wave's own earlier writes need no barrier
         if (n_mine) {
@@ -671,11 +700,6 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
                 for (int i = 0; i < 9; ++i) cacc[i] = fmaf(dcv, ob[i], cacc[i]);
             }
         }
-    };
-    for (int ti = 0; ti < tiles_per_wave; ++ti) {   // two workgroups per CU hide the load latency instead
-        TileIn tA;
-        load_tile(tA, ti);
-        process_tile(tA, ti);
     }
 
     PRISM_STAMP(10);
@@ -686,9 +710,9 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     {
         float *mine = red + (w * BWD_ACC) * 64 + lane;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mine[(kt * 4 + r) * 64] = accWphi[kt][r];
+            for (int r = 0; r < 4; ++r) mine[(c * 4 + r) * 64] = accWphi[c][r];
 #pragma unroll
         for (int mt = 0; mt < NHT; ++mt)
 #pragma unroll
@@ -706,29 +730,28 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     }
     __syncthreads();
     float *slab = a.ws.slabs + (int64_t)rc * a.slab;
-    // slot = w + 4 i for this thread (256 threads = 4 slots of 64 lanes per sweep): the slot's register
-    // index r is the wave number, its tile index the sweep number -- affine addresses, no div/mod
+    // this thread (wave w, lane) writes the register index r' = w of every accumulator: affine addresses
     auto fold4 = [&](int slot) {
         return ((red[(0 * BWD_ACC + slot) * 64 + lane] + red[(1 * BWD_ACC + slot) * 64 + lane]) +
                 red[(2 * BWD_ACC + slot) * 64 + lane]) + red[(3 * BWD_ACC + slot) * 64 + lane];
     };
     {
-        // accWphi[kt][r = w]: row (n index) = 4*g + r, col (basis) = 16*kt + j
-        float *dst = slab + (int64_t)(cs * 16 + 4 * g + w) * K_BASIS + j;
-        float v[4];
+        // accWphi[c][r' = w]: row n = cs*16 + 4g + w, basis k = 4j + c  -> one 16-byte store
+        f32x4 v;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) v[kt] = fold4(w + 4 * kt);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) __builtin_nontemporal_store(v[kt], dst + 16 * kt);
+        for (int c = 0; c < 4; ++c) v[c] = fold4(c * 4 + w);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(slab + (int64_t)(cs * 16 + 4 * g + w) * K_BASIS + 4 * j));
     }
     {
-        // accW1[mt][r = w]: row h = 16*mt + 4*g + r, col n = cs*16 + j
-        float *dst = slab + (int64_t)SLAB_W1 + (int64_t)(4 * g + w) * E_DIM + cs * 16 + j;
+        // accW1[4u + c][r' = w]: row h = 16g + 4w + 64u + c, col n = cs*16 + j
+        float *dst = slab + (int64_t)SLAB_W1 + (int64_t)(16 * g + 4 * w) * E_DIM + cs * 16 + j;
         float v[NHT];
 #pragma unroll
         for (int mt = 0; mt < NHT; ++mt) v[mt] = fold4(16 + w + 4 * mt);
 #pragma unroll
-        for (int mt = 0; mt < NHT; ++mt) __builtin_nontemporal_store(v[mt], dst + (int64_t)16 * mt * E_DIM);
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) __builtin_nontemporal_store(v[4 * u + c], dst + (int64_t)(64 * u + c) * E_DIM);
     }
     if (w < 3 && g == 0) {
         const float v = fold4(16 + 4 * NHT + w);

@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 UPDATE_CASES = ["iqn_small", "iqn_c3", "dqn_c2", "dqn_ln", "dqn_target_c2", "full_c4", "full_small",
-                "full_notarget", "full_doubleq", "iqn_target", "iqn_doubleq", "iqn_tau32"]
+                "full_notarget", "full_doubleq", "iqn_target", "iqn_doubleq", "iqn_tau32",
+                # the reference's ablation presets and the stages its experiment files derive from them
+                "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub"]
 
 
 def load_case(name):
@@ -22,11 +24,13 @@ def case_overrides(g):
 
 
 def case_config(g, device="cpu", **extra):
-    from prism_amd.config import MINATAR_CONFIG, derive
+    from prism_amd import config as C
+    base = {"minatar": C.MINATAR_CONFIG, "additive": C.ADDITIVE_ABLATION_BASE_CONFIG,
+            "subtractive": C.SUBTRACTIVE_ABLATION_BASE_CONFIG}[str(g["base"]) if "base" in g else "minatar"]
     kw = dict(device=device, use_cuda_graph=False, use_e_greedy=False)
     kw.update(case_overrides(g))
     kw.update(extra)
-    return derive(MINATAR_CONFIG, **kw)
+    return C.derive(base, **kw)
 
 
 def case_batch(g, step):

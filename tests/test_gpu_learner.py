@@ -46,7 +46,9 @@ def to_hip_batch(batch, dev):
 
 IQN_CASES = ["iqn_small", "iqn_c3", "iqn_tau32", "iqn_target", "iqn_doubleq",
              "full_small", "full_notarget", "full_doubleq", "full_c4",
-             "dqn_c2", "dqn_ln", "dqn_target_c2"]
+             "dqn_c2", "dqn_ln", "dqn_target_c2",
+             # the reference's ablation presets / experiment stages: width 256, T = 32, LayerNorm off or on
+             "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub"]
 
 
 @pytest.mark.parametrize("name", IQN_CASES)
@@ -58,11 +60,13 @@ def test_iqn_update_matches_reference_and_oracle(dev, name):
     s0 = np.array([float(v.double().sum()) for v in agent.model.state_dict().values()])
     np.testing.assert_array_equal(s0, g["init_sum"])
     cpu_cfg = H.case_config(g)
-    sd, tgt = H.build_init_state(cpu_cfg, int(g["seed"]))
-    orc = LearnerOracle(sd, H.spec_from_config(cpu_cfg), tgt)
+    sd, tgt = H.build_init_state(cpu_cfg, int(g["seed"]), C=int(g["C"]), A=int(g["A"]))
+    orc = LearnerOracle(sd, H.spec_from_config(cpu_cfg, C=int(g["C"]), A=int(g["A"])), tgt)
     names = list(sd.keys())
+    kink_total = 0
     for step in range(int(g["steps"])):
         batch, w, taus = H.case_batch(g, step)
+        g64 = orc.grads_fp64(batch, w, taus)             # same gradient in float64, at the pre-update parameters
         td_o = orc.update(batch, w, taus)
         td = agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev), taus=[t.to(dev) for t in taus])
         torch.cuda.synchronize()
@@ -79,28 +83,46 @@ def test_iqn_update_matches_reference_and_oracle(dev, name):
             assert abs(float(agent.scalars[4]) - float(g[pre + "theil"])) < 1e-6
         assert abs(float(agent._static_total_loss) - float(g[pre + "total"])) < LOSS_TOL
         np.testing.assert_allclose(td.cpu().numpy(), td_o.numpy(), rtol=0, atol=LOSS_TOL)
-        # gradients vs oracle autograd (unclipped)
+        # gradients vs oracle autograd (unclipped).  A ReLU input within fp32 rounding distance of zero makes two
+        # correct evaluations of the SAME gradient differ by that unit's whole contribution: the oracle's own fp32 and
+        # fp64 results disagree wherever such units exist (abl_iqn, LayerNorm off: 16-19 of the 524 288 trunk
+        # pre-activations of a step sit within 1e-6 of zero and 2-3 change sign between fp32 and fp64; 1.7e-5 on the
+        # conv weight, 0.2 % of its largest element), and a kernel with another summation order may land on yet
+        # another side.  So the tolerance of a tensor grows by twice the oracle's own fp32/fp64 disagreement on it
+        # (1e-8-ish where no unit is kink-adjacent), and the (tensor, step) pairs that needed the allowance are counted.
         off = 0
         gflat = agent.grads.cpu()
+        kinked, allowance = {}, {}
         for k in names:
             n = sd[k].numel()
             go = orc.last["grads"][k].reshape(-1)
             gh = gflat[off:off + n]
             tol = 1e-4 * float(go.abs().max()) + 1e-7
-            err = float((gh - go).abs().max())
-            assert err <= tol, f"step {step} grad {k}: max err {err:.3e} > {tol:.3e}"
+            kink = 2.0 * float((go.double() - g64[k].reshape(-1)).abs().max())
+            allowance[k] = kink
+            err32 = float((gh - go).abs().max())
+            err64 = float((gh.double() - g64[k].reshape(-1)).abs().max())
+            err = min(err32, err64)
+            if err > tol:
+                kinked[k] = err
+            assert err <= tol + kink, f"step {step} grad {k}: max err {err32:.3e} (vs fp64: {err64:.3e}) > {tol:.3e} + {kink:.3e}"
             off += n
+        kink_total += len(kinked)
         assert abs(float(agent.scalars[3]) - float(orc.last["grad_norm"])) < 1e-4 * max(1.0, float(orc.last["grad_norm"]))
         # parameters after the Adam step: vs oracle and vs the reference's checksums
         post = agent.model.state_dict()
         for k, v in orc.state_dict().items():
-            np.testing.assert_allclose(post[k].cpu().numpy(), v.numpy(), rtol=0, atol=2e-6, err_msg=k)
+            # (where units are kink-adjacent, the Adam step of an element differs by up to lr * |dg| / adam_eps)
+            atol = 2e-6 + cfg.learning_rate * allowance[k] / cfg.adam_epsilon
+            np.testing.assert_allclose(post[k].cpu().numpy(), v.numpy(), rtol=0, atol=atol, err_msg=k)
         l2 = np.array([float(v.double().norm()) for v in post.values()])
         np.testing.assert_allclose(l2, g[pre + "post_l2"], rtol=2e-6, atol=1e-7)
         if cfg.use_target_network and step == 0:
             agent.sync_target_model()
             orc.sync_target()
     assert int(agent.optimizer.step_t.item()) == int(g["steps"])
+    # only the LayerNorm-free width-256 network (un-normalised trunk input, half a million ReLU units per step) may need it
+    assert kink_total == 0 or not cfg.use_layer_norm, f"{kink_total} (tensor, step) pairs needed the kink allowance"
 
 
 def test_philox_taus_are_uniform_and_recorded(dev):
@@ -117,8 +139,8 @@ def test_philox_taus_are_uniform_and_recorded(dev):
     # replaying the recorded taus through the oracle reproduces the in-kernel-RNG step
     from oracle.learner_ref import LearnerOracle
     cpu_cfg = H.case_config(g)
-    sd, tgt = H.build_init_state(cpu_cfg, int(g["seed"]))
-    orc = LearnerOracle(sd, H.spec_from_config(cpu_cfg), tgt)
+    sd, tgt = H.build_init_state(cpu_cfg, int(g["seed"]), C=int(g["C"]), A=int(g["A"]))
+    orc = LearnerOracle(sd, H.spec_from_config(cpu_cfg, C=int(g["C"]), A=int(g["A"])), tgt)
     taus = [t1[0, :T * B].cpu().reshape(-1, 1), t1[1, :T * B].cpu().reshape(-1, 1)]
     td_o = orc.update(batch, w, taus)
     np.testing.assert_allclose(td1.cpu().numpy(), td_o.numpy(), rtol=0, atol=LOSS_TOL)

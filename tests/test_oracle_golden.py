@@ -14,7 +14,7 @@ LOSS_TOL = 1e-5       # BASELINE.json: loss parity to reference within 1e-5
 def test_oracle_matches_reference_update(name):
     g = H.load_case(name)
     cfg = H.case_config(g)
-    sd, tgt = H.build_init_state(cfg, int(g["seed"]))
+    sd, tgt = H.build_init_state(cfg, int(g["seed"]), C=int(g["C"]), A=int(g["A"]))
     s0, l0 = H.checksums(sd)
     assert list(sd.keys()) == list(g["param_names"])
     np.testing.assert_array_equal(s0, g["init_sum"])           # init parity is exact
@@ -23,7 +23,7 @@ def test_oracle_matches_reference_update(name):
         for k in sd:
             np.testing.assert_array_equal(sd[k].numpy(), g["init/" + k])
 
-    orc = LearnerOracle(sd, H.spec_from_config(cfg), tgt)
+    orc = LearnerOracle(sd, H.spec_from_config(cfg, C=int(g["C"]), A=int(g["A"])), tgt)
     for step in range(int(g["steps"])):
         batch, w, taus = H.case_batch(g, step)
         td = orc.update(batch, w, taus)

@@ -91,24 +91,47 @@ CASES = {
                     32, 2, False),
     "iqn_tau32": (dict(use_ids=False, use_iqn=True, iqn_n_current_state_quantile_samples=32,
                        iqn_n_next_state_quantile_samples=32), 16, 2, False),
+    # ---- the ablation presets the reference ships (prism/config/{additive,subtractive}_ablation_base_config.py)
+    # and the stages its experiment files derive from them (additive_ablation_experiment.py:31-162,
+    # subtractive_ablation_experiment.py:30-52), at their own batch size (64), T = 32, width 256.
+    # "base" picks the preset; the remaining keys are the stage's overrides.  "C" = observation channels
+    # (MinAtar games: Breakout/Asterix 4, SpaceInvaders 6, Freeway 7, Seaquest 10).
+    "abl_iqn": (dict(base="additive"), 64, 2, False),
+    "abl_ln_notarget": (dict(base="additive", use_layer_norm=True, use_target_network=False), 64, 2, False),
+    "abl_doubleq": (dict(base="additive", use_target_network=True, use_double_q_learning=True, C=7), 64, 2, False),
+    "abl_ids": (dict(base="additive", use_ids=True, ids_n_q_head_model_layers=2, ids_n_q_heads=10,
+                     ids_ensemble_variation_coef=0, ids_q_head_feature_dim=256), 64, 2, False),
+    "abl_ids_var": (dict(base="additive", use_dqn=False, use_iqn=True, use_ids=True, ids_n_q_head_model_layers=2,
+                         ids_n_q_heads=10, ids_q_head_feature_dim=256, ids_ensemble_variation_coef=1e-6, C=10),
+                    64, 2, False),
+    "abl_sub": (dict(base="subtractive", use_layer_norm=True, use_per=False, use_target_network=True,
+                     target_update_period=4_000), 64, 2, False),
 }
 
 
 def gen_update_case(name, overrides, B, steps, store_full):
-    from prism.config import Config, MINATAR_CONFIG
+    from prism.config import Config, MINATAR_CONFIG, ADDITIVE_ABLATION_BASE_CONFIG, SUBTRACTIVE_ABLATION_BASE_CONFIG
     from prism.factory import agent_factory
 
-    cfg = Config(**MINATAR_CONFIG.__dict__)
+    overrides = dict(overrides)
+    base = overrides.get("base", "minatar")
+    C = overrides.pop("C", 4)
+    A = 6
+    preset = {"minatar": MINATAR_CONFIG, "additive": ADDITIVE_ABLATION_BASE_CONFIG,
+              "subtractive": SUBTRACTIVE_ABLATION_BASE_CONFIG}[base]
+    cfg = Config(**preset.__dict__)
     cfg.device, cfg.use_cuda_graph, cfg.use_e_greedy = "cpu", False, False
     for k, v in overrides.items():
-        setattr(cfg, k, v)
-    C, A = 4, 6
+        if k != "base":
+            setattr(cfg, k, v)
     torch.manual_seed(cfg.seed)
     with contextlib.redirect_stdout(io.StringIO()):
         agent = agent_factory.build_agent(cfg, (10, 10, C), A)
     out = {"seed": cfg.seed, "B": B, "steps": steps, "C": C, "A": A}
-    out["overrides_keys"] = np.array(list(overrides.keys()))
-    out["overrides_vals"] = np.array([repr(v) for v in overrides.values()])
+    ov = {k: v for k, v in overrides.items() if k != "base"}
+    out["base"] = base
+    out["overrides_keys"] = np.array(list(ov.keys()))
+    out["overrides_vals"] = np.array([repr(v) for v in ov.values()])
     names, s0, l0 = tensor_stats(agent.model.state_dict())
     out["param_names"] = np.array(names)
     out["init_sum"], out["init_l2"] = s0, l0
@@ -279,9 +302,24 @@ def gen_config_snapshot():
     """Field names / order / preset values of the reference's Config, as data."""
     import dataclasses
     import json
-    from prism.config import Config, DEFAULT_CONFIG, MINATAR_CONFIG
+    from prism.config import (Config, DEFAULT_CONFIG, MINATAR_CONFIG, ADDITIVE_ABLATION_BASE_CONFIG,
+                              SUBTRACTIVE_ABLATION_BASE_CONFIG)
     snap = {"fields": [f.name for f in dataclasses.fields(Config)],
-            "DEFAULT_CONFIG": DEFAULT_CONFIG.__dict__, "MINATAR_CONFIG": MINATAR_CONFIG.__dict__}
+            "DEFAULT_CONFIG": DEFAULT_CONFIG.__dict__, "MINATAR_CONFIG": MINATAR_CONFIG.__dict__,
+            "ADDITIVE_ABLATION_BASE_CONFIG": ADDITIVE_ABLATION_BASE_CONFIG.__dict__,
+            "SUBTRACTIVE_ABLATION_BASE_CONFIG": SUBTRACTIVE_ABLATION_BASE_CONFIG.__dict__}
+    # every configuration the two experiment files generate, as {group name: fields that differ from the base}
+    # (seed 0 of each group; seeds only change `seed` / names / checkpoint_dir)
+    from prism.experiments.experiment_files.additive_ablation_experiment import AdditiveAblationExperiment
+    from prism.experiments.experiment_files.subtractive_ablation_experiment import SubtractiveAblationExperiment
+    skip = {"seed", "wandb_project_name", "wandb_group_name", "wandb_run_name", "checkpoint_dir"}
+    for key, exp_cls, base in (("ADDITIVE_STAGES", AdditiveAblationExperiment, ADDITIVE_ABLATION_BASE_CONFIG),
+                               ("SUBTRACTIVE_STAGES", SubtractiveAblationExperiment, SUBTRACTIVE_ABLATION_BASE_CONFIG)):
+        stages = {}
+        for cfg in exp_cls(num_seeds=1).configs:
+            diff = {k: v for k, v in cfg.__dict__.items() if k not in skip and base.__dict__.get(k) != v}
+            stages[cfg.wandb_group_name] = diff
+        snap[key] = stages
     with open(os.path.join(OUT, "config_presets.json"), "w") as f:
         json.dump(snap, f, indent=1, sort_keys=True)
     print("config_presets:", len(snap["fields"]), "fields")

@@ -21,21 +21,35 @@ ag._desc.dbg_stamps = st.data_ptr()
 def run():
     st.zero_(); ln.step(eager=True); torch.cuda.synchronize(); return st.cpu().numpy().reshape(4096, 64)
 s = run()
-f = s[:256, :8].astype(np.float64)
-names = ["weights issue, tau, cos basis", "phi GEMM (K=64) + epilogue", "barrier", "LayerNorm(1024)", "trunk GEMM (K=1024)", "fold of the K slices", "LayerNorm(128) + head"]
-print("tile_fwd (median over 256 workgroups, shader-clock ticks):")
-for k in range(7):
-    print(f"   {names[k]:24s} {np.median(f[:, k + 1] - f[:, k]):9.0f}")
-print(f"   total {np.median(f[:, 7] - f[:, 0]):9.0f}   start spread {f[:, 0].max() - f[:, 0].min():9.0f}   end spread {f[:, 7].max() - f[:, 7].min():9.0f}")
-ow = s[s[:, 33] != 0][:, [7, 32, 33]].astype(np.float64)
-n_pub = int((s[:, 32] != 0).sum()) - len(ow)
-if len(ow): print("   fused loss tail of the current-state tiles (barrier | loss of the tile's samples, incl. the wait for the publishers):", [int(np.median(ow[:, k + 1] - ow[:, k])) for k in range(2)], f"({len(ow)} consumer tiles, {n_pub} publisher tiles)")
+nfw = int((s[:, 0] != 0).sum())
+f = s[:nfw, :7].astype(np.float64)
+names = ["first requests, tau, cos basis", "streamed phi + trunk products", "partials out + barrier", "fold, LayerNorm, head",
+         "loss of the tile's samples", "head/LN backward + per-sample sums"]
+print(f"fwd_tile ({nfw} workgroups; median shader-clock ticks):")
+for k in range(6):
+    d = f[:, k + 1] - f[:, k]
+    d = d[f[:, k + 1] != 0]
+    if len(d): print(f"   {names[k]:36s} {np.median(d):9.0f}   (min {d.min():7.0f} max {d.max():7.0f})")
+last = np.where(f[:, 6] != 0, f[:, 6], f[:, 4])
+dur = last - f[:, 0]
+def rt_spans(start, end):
+    """slots 32 + k: the chip-wide 100 MHz real-time counter at stamp k (10 ns ticks) -> microseconds"""
+    return (start.max() - start.min()) / 100.0, (end.max() - start.min()) / 100.0
+rl = np.where(s[:nfw, 38] != 0, s[:nfw, 38], s[:nfw, 36]).astype(np.float64)
+ss, sp = rt_spans(s[:nfw, 32].astype(np.float64), rl)
+print(f"   workgroup total: median {np.median(dur):9.0f}  p95 {np.percentile(dur, 95):9.0f}  max {dur.max():9.0f};  start spread {ss:6.2f} us   "
+      f"first start -> last end {sp:6.2f} us")
 nb = int((s[:, 8] != 0).sum())
 b = s[:nb, 8:13].astype(np.float64)
 print(f"bwd ({nb} workgroups):")
 for k, name in enumerate(["consts", "tile loop", "barrier", "reduce+write"]):
     print(f"   {name:24s} {np.median(b[:, k + 1] - b[:, k]):9.0f}")
-print(f"   total {np.median(b[:, 4] - b[:, 0]):9.0f}   start spread {b[:, 0].max() - b[:, 0].min():9.0f}  end spread {b[:, 4].max() - b[:, 4].min():9.0f}")
+bend = np.where(s[:nb, 26] != 0, s[:nb, 26], s[:nb, 12]).astype(np.float64)
+bd = bend - b[:, 0]
+rl = np.where(s[:nb, 58] != 0, s[:nb, 58], s[:nb, 44]).astype(np.float64)
+ss, sp = rt_spans(s[:nb, 40].astype(np.float64), rl)
+print(f"   workgroup total: median {np.median(bd):9.0f}  p95 {np.percentile(bd, 95):9.0f}  max {bd.max():9.0f};  start spread {ss:6.2f} us   "
+      f"first start -> last end {sp:6.2f} us")
 bt = s[:nb, [12, 26]].astype(np.float64)
 if bt[:, 1].any(): print("   conv tail:", int(np.median(bt[:, 1] - bt[:, 0])))
 
@@ -74,10 +88,7 @@ order = np.argsort(-d_)[:10]
 print("   longest post blocks (index: ticks):", ", ".join(f"{int(idx[i])}: {int(d_[i])}" for i in order))
 print("   post block duration by index decile:", [int(np.median(d_[(idx >= lo_) & (idx < hi_)])) if ((idx >= lo_) & (idx < hi_)).any() else 0
       for lo_, hi_ in zip(np.linspace(0, idx.max() + 1, 11)[:-1], np.linspace(0, idx.max() + 1, 11)[1:])])
-# tile_fwd per launch-order range (passes differ in cost: IQN publisher / consumer tiles, Q-head tiles)
-tb = s[:, [0, 7]].astype(np.float64)
-tb = tb[tb[:, 0] != 0]
-if len(tb) > 256:
-    d = tb[:, 1] - tb[:, 0]
-    q = len(d) // 8
-    print("tile_fwd block duration by launch-order octile:", [int(np.median(d[i * q:(i + 1) * q])) for i in range(8)], f"({len(d)} tiles)")
+if os.environ.get("STAMP_DEBUG"):
+    v = np.sort(s[:nfw, 0].astype(np.int64))
+    print("fwd start stamps sorted (first 6, last 6):", v[:6], v[-6:])
+    print("fwd rows with zero start:", np.nonzero(s[:nfw, 0] == 0)[0][:10], " nfw", nfw, " nonzero rows beyond:", np.nonzero(s[nfw:, 0])[0][:5])
