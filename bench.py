@@ -41,26 +41,30 @@ def algorithmic_bytes(cfg, P, P_tgt, cap2_levels):
 
 
 def kernel_flops(cfg, B, A=6):
-    """Algorithmic flops per launch of the two GEMM kernels."""
-    T, Tn, E, K, H = cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples, 1024, 64, 128
+    """ALGORITHMIC flops per launch of the GEMM kernels: forward = phi + trunk + head of every
+    row; backward = dW of phi, dW and dX of the trunk (the phi columns the backward kernel recomputes instead of
+    reading them back are not algorithmic work and are not counted)."""
+    T, Tn, E, K = cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples, 1024, 64
+    H = cfg.iqn_quantile_model_feature_dim
     n_next = 2 if (cfg.use_target_network and cfg.use_double_q_learning) else 1
     fwd = bwd = qbwd = 0
     if cfg.use_iqn:
         fwd += (B * T + n_next * B * Tn) * (2 * K * E + 2 * E * H + 2 * H * A)
-        bwd += B * T * 2 * E * (K + H + K + H)
+        bwd += B * T * 2 * E * (K + H + H)
     heads = cfg.ids_n_q_heads if cfg.use_ids else (1 if cfg.use_dqn and cfg.dqn_n_model_layers == 2 else 0)
     if heads:
+        H = cfg.ids_q_head_feature_dim if cfg.use_ids else cfg.dqn_n_model_feature_dim
         fwd += (1 + n_next) * B * heads * (2 * E * H + 2 * H * A)
         qbwd += B * heads * 2 * E * (H + H)
-    fl = {"iqn_tile_fwd_kernel": fwd}
+    fl = {"fwd_tile_kernel": fwd}
     if bwd:
         fl["iqn_bwd_kernel"] = bwd
     if qbwd:
-        fl["q_bwd_kernel"] = qbwd
+        fl["qh_bwd_kernel"] = qbwd
     return fl
 
 
-def cpu_baseline(cfg, seconds=12.0):
+def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle port of the same step (C sum tree + n-step gather, torch-CPU TD update)."""
     import contextlib
     import io
@@ -103,16 +107,26 @@ def cpu_baseline(cfg, seconds=12.0):
         td = orc.update(batch, torch.from_numpy(w), taus)
         rp.sampler.update_priority(idx, td.abs().numpy())
 
-    for _ in range(3):
-        one()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of the same workload (B={B}, replay {cap}) in {dt:.1f} s: C sum-tree sample + "
-                      f"n-step gather + torch-CPU TD update + priority writeback"}
+    # thread sweep (oversubscribing a many-core host thrashes: the rate at nproc threads is NOT the best one)
+    nproc = os.cpu_count() or 1
+    sweep = sorted({t for t in (1, 8, 16, 32, min(nproc, 64)) if t <= nproc})     # (256 threads: 12 s per step, pure thrash)
+    per = max(1.5, seconds / len(sweep))
+    rates = {}
+    for th in sweep:
+        torch.set_num_threads(th)
+        for _ in range(2):
+            one()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < per:
+            one()
+            n += 1
+        rates[th] = n / (time.perf_counter() - t0)
+    best = max(rates, key=rates.get)
+    torch.set_num_threads(nproc)
+    return {"value": round(rates[best], 3), "unit": "steps/s", "cores": nproc, "threads": best, "kind": "port",
+            "one_thread": round(rates[1], 3), "by_threads": {str(k): round(v, 3) for k, v in rates.items()},
+            "sample": f"the same workload (B={B}, replay {cap}) for {per:.1f} s at each of {sweep} torch threads: C sum-tree "
+                      f"sample + n-step gather + torch-CPU TD update + priority writeback; value = best, one_thread = 1 thread"}
 
 
 def main():
@@ -123,7 +137,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i]; 2 = the metric's config")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-every", type=int, default=16)
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0: enough for ~2000 steps)")
+    ap.add_argument("--profile-steps", type=int, default=128, help="eager, HIP-event instrumented steps after the timing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -193,21 +208,30 @@ def main():
     L.prism_profile_collect(ms, cnt)
     for i in range(N.N_KERNEL_IDS):
         ms[i], cnt[i] = 0.0, 0
-    pe = max(1, args.profile_every)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % pe == pe - 1:
-            L.prism_profile_enable(1)
-            learner.step(eager=True)
-            L.prism_profile_enable(0)
-        else:
+    # timed region: `repeats` blocks of EXACTLY `steps` steps each, every block bracketed by barrier + synchronize;
+    # the reported rate is the median block (a 20-step block is 2 ms: one block alone is mostly noise)
+    repeats = args.repeats if args.repeats > 0 else min(200, max(5, -(-2000 // max(1, args.steps))))
+    blocks = []
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
             learner.step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        blocks.append(dt)
+    elapsed = float(np.median(blocks))
+    # per-kernel durations: HIP events on the launch stream around every launch of `profile_steps` eager steps
+    # (outside the timed blocks: the events cost ~2 us per launch)
+    L.prism_profile_enable(1)
+    for _ in range(args.profile_steps):
+        learner.step(eager=True)
+    L.prism_profile_enable(0)
     sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
     L.prism_profile_collect(ms, cnt)
 
     if rank == 0:
@@ -251,6 +275,8 @@ def main():
                else f"learner grad-steps/sec, BASELINE configs[{args.config}]",
                "value": round(args.steps * world / elapsed, 2), "unit": "steps/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
+               "repeats": repeats, "timing": "median of `repeats` blocks of `steps` steps; min/max block ms_per_step: "
+               f"{min(blocks) / args.steps * 1e3:.5f}/{max(blocks) / args.steps * 1e3:.5f}",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": f"configs[{args.config}]: " + ["DQN + uniform replay, batch=32",

@@ -186,7 +186,8 @@ class HipAgent:
         self.tau_rng = getattr(config, "tau_rng", "philox")
         self.overlap_writeback = bool(getattr(config, "overlap_writeback", True))
         self.seed = int(config.seed)
-        self._draw_offset = 0
+        self._draw_offset = 0      # tau counters consumed by update() (host-issued offsets)
+        self._fused_tau = 0        # ... and by fused steps (device counter, mirrored: one counter space for both paths)
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -225,7 +226,6 @@ class HipAgent:
         d.out_dist_loss, d.out_q_loss = self.out_dl.data_ptr(), self.out_ql.data_ptr()
         d.out_td, d.out_scalars = self.out_td.data_ptr(), self.scalars.data_ptr()
         d.workspace, d.workspace_bytes = self.workspace.data_ptr(), ws_bytes
-        d.seed = self.seed
         self.rng_counters = torch.zeros(2, dtype=torch.int64, device=dev)     # {PER draws, tau draws}
         self._desc, self._B = d, B
         self._graphs = {}
@@ -285,7 +285,8 @@ class HipAgent:
                 d.tau_next_online = next(it).data_ptr()
             if self.dims.has_target:
                 d.tau_next_target = next(it).data_ptr()
-        d.offset = self._draw_offset
+        d.seed = self.seed
+        d.offset = self._draw_offset + self._fused_tau
         d.rng_counters, d.embed_done, d.fused_replay = None, 0, None
         self._draw_offset += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * B
         self._set_hyper()
@@ -314,6 +315,7 @@ class HipAgent:
         d.gamma, d.action = buf._gamma.data_ptr(), buf._action.data_ptr()
         d.per_weights = buf._weight.data_ptr() if buf.use_per else None
         d.tau_cur = d.tau_next_online = d.tau_next_target = None
+        d.seed = self.seed
         self._set_hyper()
         return d
 
@@ -328,7 +330,7 @@ class HipAgent:
             d.fused_replay = None
         if part in ("all", "front"):
             d.embed_done = 1
-            N.check(L.prism_step_front(ctypes.byref(d), rp, buf._size, None, buf.seed, d.offset,
+            N.check(L.prism_step_front(ctypes.byref(d), rp, buf._size, None, buf.seed, buf._draws,
                                        buf.buffer._sampler._beta, N.ptr(buf._index), N.ptr(buf._weight), st()),
                     "prism_step_front")
             N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), st()), "prism_learner_fwd_bwd")
@@ -349,15 +351,20 @@ class HipAgent:
             buf._alloc_batch(buf.buffer._batch_size)
         d = self._bind_fused(buf)
         d.rng_counters = self.rng_counters.data_ptr()
-        d.offset = 0
+        d.offset = self._draw_offset               # device counter + what update() has consumed: never the same draw twice
         graphable = use_graph and not eager and buf._size == buf.capacity
         with torch.cuda.device(self.device):
             if not graphable:
                 self._launch_fused(buf, d)
             else:
-                key = (id(buf), buf._size, self.world)
+                # a captured graph bakes every by-value launch argument: hyper-parameters, seeds, beta / alpha, offsets
+                h, smp = d.hyper, buf.buffer._sampler
+                key = (id(buf), buf._size, self.world, h.lr, h.beta1, h.beta2, h.eps, h.max_grad_norm, h.grad_scale,
+                       self.seed, buf.seed, smp._beta, smp._alpha, smp._eps, self._draw_offset, buf._draws,
+                       self.overlap_writeback)
                 g = self._graphs.get(key)
                 if g is None:
+                    self._graphs.clear()                        # arguments changed: older captures are stale
                     self._launch_fused(buf, d)                  # first full-buffer step runs eagerly
                     self._graphs[key] = "warm"
                 elif g == "warm":
@@ -365,6 +372,8 @@ class HipAgent:
                     self._graphs[key] = self._capture(buf, d)   # capture, then replay once = this step
                 else:
                     self._replay(g, buf, d)
+        self._fused_tau += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * self._B
+        buf._fused_draws += self._B
         self._static_total_loss = self.scalars[0]
         self._static_distribution_loss = self.out_dl if self.dims.use_iqn else None
         self._static_q_loss = self.out_ql if self.dims.n_heads > 0 else None

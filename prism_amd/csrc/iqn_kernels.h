@@ -450,23 +450,33 @@ __host__ __device__ constexpr int bwd_acc(int H) { return 16 + H / 4 + 3; }     
 constexpr int BWD_CONV_TAPS = 18;                   // taps per lane: 9 * C / share
 constexpr int BWD_CONV_ROW = 96;                    // floats per partial row: 9C taps (C <= 10) + bias
 __host__ __device__ constexpr int bwd_w_lds(int H) { return 16 * K_BASIS + 16 * H; }        // Wphi slice | W1 slice, operand order
-__host__ __device__ constexpr int bwd_main_lds(int H) {
-    return 4 * bwd_acc(H) * 64 > bwd_w_lds(H) ? 4 * bwd_acc(H) * 64 : bwd_w_lds(H);
-}
-constexpr int BWD_CONV_PRE4 = 12;                   // float4 registers per lane staging the wave's observation rows
 __host__ __device__ inline int bwd_conv_share(int T) { return T == 4 ? 1 : (T == 8 ? 2 : 4); }
 // samples one wave may own (its observation rows are staged in LDS: 4 image rows x 10 x C floats each)
 __host__ __device__ inline int bwd_conv_spw(int B, int n_chunks) { return (B + 4 * n_chunks - 1) / (4 * n_chunks) + 1; }
-__host__ __device__ inline int bwd_conv_lds_floats(int B, int C, int n_chunks) {
-    return 4 * BWD_CONV_ROW + 4 * bwd_conv_spw(B, n_chunks) * 40 * C;
+// tiles one wave may walk (their d e values are parked in LDS for the tap pass behind the tile loop)
+__host__ __device__ inline int bwd_tiles_per_wave(int B, int T, int n_chunks) {
+    return (B * T / 16 + 4 * n_chunks - 1) / (4 * n_chunks) + (T > 16 ? T / 16 : 1);
+}
+constexpr int BWD_CONV_PRE = 12;                    // 16-byte LDS-DMA pieces per lane staging a wave's observation rows
+// LDS of a workgroup: [ weight slices | observation rows | d e values ] during the tile loop, overlaid afterwards by
+// the cross-wave reduction buffer; the conv tap fold has a small region of its own behind it
+__host__ __device__ inline int bwd_loop_lds(int H, int B, int C, int T, int n_chunks, bool conv) {
+    return bwd_w_lds(H) + (conv ? 4 * bwd_conv_spw(B, n_chunks) * 40 * C + 4 * bwd_tiles_per_wave(B, T, n_chunks) * 64 : 0);
+}
+__host__ __device__ inline int bwd_main_lds(int H, int B, int C, int T, int n_chunks, bool conv) {
+    const int red = 4 * bwd_acc(H) * 64, loop = bwd_loop_lds(H, B, C, T, n_chunks, conv);
+    return red > loop ? red : loop;
+}
+__host__ __device__ inline int bwd_lds_floats(int H, int B, int C, int T, int n_chunks, bool conv) {
+    return bwd_main_lds(H, B, C, T, n_chunks, conv) + (conv ? 4 * BWD_CONV_ROW : 0);
 }
 __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propagate_grad, int T, int C, int B,
                                             int n_chunks, int H) {
     const int share = bwd_conv_share(T);
     return use_iqn && n_heads == 0 && propagate_grad && C % share == 0 && 9 * (C / share) <= BWD_CONV_TAPS &&
            C / share <= 2 && (C / share == 1 || C % 2 == 0) &&      // 1 channel, or an aligned pair, per lane
-           9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE4 * 64 &&
-           (bwd_main_lds(H) + bwd_conv_lds_floats(B, C, n_chunks)) * 4 <= 76 * 1024;     // two workgroups per CU
+           9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE * 64 &&
+           bwd_lds_floats(H, B, C, T, n_chunks, true) * 4 <= (H == 128 ? 76 : 152) * 1024;     // two (one) workgroups per CU
 }
 #ifndef BWD_CHUNKS
 #define BWD_CHUNKS 8
@@ -474,7 +484,7 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
 
 template <int H, bool LN>
 __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
-    constexpr int NHT = H / 16, NU = H / 64, BWD_ACC = bwd_acc(H), BWD_MAIN_LDS = bwd_main_lds(H);
+    constexpr int NHT = H / 16, NU = H / 64, BWD_ACC = bwd_acc(H);
     constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);     // slab: phi_w | phi_b | [ln1_g | ln1_b] | w1
     typedef const f32x4 __attribute__((address_space(1))) *g4;
     typedef const float __attribute__((address_space(1))) *g1p;
@@ -516,15 +526,16 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     const int C = a.C, y0 = (cs & 3) * 2;
     const int share = bwd_conv_share(T), cpl = C / share, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
     const int sub = T == 8 ? (g & 1) : g;
-    float cacc[BWD_CONV_TAPS], cbias = 0.f;
-#pragma unroll
-    for (int i = 0; i < BWD_CONV_TAPS; ++i) cacc[i] = 0.f;
     // observation rows y0..y0+3 of this wave's samples: requested first thing, straight into LDS (LDS-DMA: 16 B
     // per lane, lane-linear destination, no registers); the barrier in front of the tile loop covers them
     const int ws_lo = (tile_begin * 16) / T, ws_n = n_mine ? (tiles_per_wave * 16) / T : 0;
-    float *s_obs = smem + BWD_MAIN_LDS + 4 * BWD_CONV_ROW + w * (bwd_conv_spw(a.B, a.n_chunks) * 40 * C);
+    const int spw = bwd_conv_spw(a.B, a.n_chunks), tpw = bwd_tiles_per_wave(a.B, T, a.n_chunks);
+    float *s_obs = smem + bwd_w_lds(H) + w * (spw * 40 * C);
+    // ReLU-masked d e of every tile of this wave, consumed by the tap pass behind the tile loop (keeps the tap
+    // accumulators out of the loop's register budget)
+    float *s_dcv = smem + bwd_w_lds(H) + 4 * (spw * 40 * C) + w * tpw * 64;
 #pragma unroll
-    for (int i = 0; i < BWD_CONV_PRE4; ++i) {
+    for (int i = 0; i < BWD_CONV_PRE; ++i) {
         const int idx = lane + 64 * i;
         if (idx < ws_n * 10 * C) {
             const int s = idx / (10 * C), o4 = idx - s * 10 * C;
@@ -677,10 +688,18 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
                 de_acc = 0.f;
             }
         }
-        if (sub == 0) cbias += dcv;
-        // conv taps of (sample bsm, channel cs>>2, output position (y0 + (j>>3), j&7)); LDS reads of
-        // this wave's own earlier writes need no barrier
-        if (n_mine) {
+        if (n_mine) s_dcv[ti * 64 + lane] = dcv;
+    }
+    // ---- conv taps of (sample, channel cs>>2, output position (y0 + (j>>3), j&7)) for every tile of this wave;
+    // LDS reads of this wave's own earlier writes need no barrier
+    float cacc[BWD_CONV_TAPS], cbias = 0.f;
+#pragma unroll
+    for (int i = 0; i < BWD_CONV_TAPS; ++i) cacc[i] = 0.f;
+    if (n_mine) {
+        for (int ti = 0; ti < tiles_per_wave; ++ti) {
+            const int bsm = ((tile_begin + ti) * 16 + 4 * g) / T;
+            const float dcv = s_dcv[ti * 64 + lane];
+            if (sub == 0) cbias += dcv;
             const float *src = s_obs + (bsm - ws_lo) * 40 * C + ((j >> 3) * 10 + (j & 7)) * C + sub * cpl;
             // all reads of a lane issue back to back (no per-tap branches), then the FMAs
             if (cpl == 2) {
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     if (!n_mine) return;
     // ---- conv-backward partial row of this block: fold lanes (16 positions, then the lane groups that
     // hold the same taps for other samples), then the four waves in fixed order
-    float *s_tap = smem + BWD_MAIN_LDS;                  // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
+    float *s_tap = smem + bwd_main_lds(H, a.B, C, T, a.n_chunks, true);   // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
     constexpr int TS = BWD_CONV_TAPS + 1;
 #pragma unroll
     for (int i = 0; i < TS; ++i) {

@@ -576,7 +576,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
             constexpr int HH = decltype(h)::value;
             constexpr bool LL = decltype(l)::value;
-            const size_t lds = (size_t)(bwd_main_lds(HH) + (a.conv_in_bwd ? bwd_conv_lds_floats(B, a.C, N_CHUNKS) : 0)) * sizeof(float);
+            const size_t lds = (size_t)bwd_lds_floats(HH, B, a.C, a.T, N_CHUNKS, a.conv_in_bwd != 0) * sizeof(float);
             herr = set_max_lds((const void *)iqn_bwd_kernel<HH, LL>, lds);
             if (herr == hipSuccess)
                 hipLaunchKernelGGL((iqn_bwd_kernel<HH, LL>), dim3((E_DIM / 16) * N_CHUNKS), dim3(256), lds, stream, a);

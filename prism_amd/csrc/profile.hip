@@ -70,10 +70,10 @@ extern "C" int prism_profile_collect(double *ms_sum, int64_t *count) {
 
 extern "C" const char *prism_profile_kernel_name(int id) {
     static const char *names[PRISM_N_KERNEL_IDS] = {
-        "iqn_embed_kernel", "iqn_tile_fwd_kernel", "iqn_loss_kernel",      "iqn_bwd_kernel",
+        "iqn_embed_kernel", "fwd_tile_kernel",     "iqn_loss_kernel",      "iqn_bwd_kernel",
         "iqn_post_kernel",  "step_front_kernel",   "clip_adam_kernel",     "per_sample_kernel",
-        "replay_gather_kernel", "per_update_kernel", "step_back_kernel",   "q_loss_kernel",
-        "q_bwd_kernel",     "",                    "",                     ""};
+        "replay_gather_kernel", "per_update_kernel", "step_back_kernel",   "qh_loss_kernel",
+        "qh_bwd_kernel",     "",                    "",                     ""};
     if (id < 0 || id >= PRISM_N_KERNEL_IDS) return "";
     return names[id];
 }

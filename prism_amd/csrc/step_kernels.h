@@ -358,8 +358,11 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         __shared__ int s_last;
         conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
         PRISM_STAMP(20);
-        // publish, then let the last arriver fold all partial rows: ONE lane releases after the
-        // block's stores have drained (the barrier waits for them), ONE lane acquires
+        // publish, then let the last arriver fold all partial rows (the placement-independent hand-off of the
+        // CDNA guide): EVERY storing wave drains its stores (a barrier alone only proves they were issued),
+        // the workgroup barrier, then ONE lane releases (L2 write-back), waits again (hipcc may drop the fence's
+        // own wait) and draws the ticket; the last arriver acquires before any of its waves reads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

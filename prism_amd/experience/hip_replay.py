@@ -84,7 +84,8 @@ class HipReplayBuffer:
         self.mass_rng, self.seed, self.strict = mass_rng, int(seed), bool(strict)
         self.buffer = _RingShim(self, batch_size, alpha, beta)
         self._size = 0
-        self._draws = 0
+        self._draws = 0            # Philox counters consumed by sample() (host-issued offsets)
+        self._fused_draws = 0      # ... and by fused steps (device counter; mirrored here so the two never overlap)
         self._obs_shape = None
         self._desc = None
         self._batch = None
@@ -246,11 +247,12 @@ class HipReplayBuffer:
                     m = np.random.uniform(0.0, p_sum, size=B).astype(np.float32)
                     self._mass.copy_(torch.from_numpy(m))
                     mass = self._mass
-                N.check(L.prism_per_sample(dsc, self._size, B, N.ptr(mass), self.seed, self._draws,
+                N.check(L.prism_per_sample(dsc, self._size, B, N.ptr(mass), self.seed, self._draws + self._fused_draws,
                                            self.buffer._sampler._beta, N.ptr(self._index), N.ptr(self._weight),
                                            st()), "prism_per_sample")
             else:
-                N.check(L.prism_uniform_sample(self._size, B, self.seed, self._draws, N.ptr(self._index), st()),
+                N.check(L.prism_uniform_sample(self._size, B, self.seed, self._draws + self._fused_draws,
+                                               N.ptr(self._index), st()),
                         "prism_uniform_sample")
             self._draws += B
             N.check(L.prism_replay_gather(dsc, N.ptr(self._index), B, N.ptr(self._obs), N.ptr(self._next_obs),

@@ -28,8 +28,9 @@ def test_gemm_flops_match_survey():
     from prism_amd.config import baseline_config
     b = _bench()
     fl = b.kernel_flops(baseline_config(2), 256)
-    # forward: 4096 rows x (2*64*1024 + 2*1024*128 + 2*128*6); backward: 2048 rows x 2*1024*384
-    assert fl["iqn_tile_fwd_kernel"] == 4096 * (2 * 64 * 1024 + 2 * 1024 * 128 + 2 * 128 * 6)
-    assert fl["iqn_bwd_kernel"] == 2048 * 2 * 1024 * 384
-    assert abs(sum(fl.values()) / 1e9 - 3.23) < 0.05     # ~2.97 GFLOP of SURVEY + dW_phi counted as a full GEMM
+    # forward: 4096 rows x (2*64*1024 + 2*1024*128 + 2*128*6); backward: 2048 rows x 2*1024*(64 + 128 + 128)
+    # (dW of phi, dW and dX of the trunk; the phi columns the kernel recomputes are not algorithmic work)
+    assert fl["fwd_tile_kernel"] == 4096 * (2 * 64 * 1024 + 2 * 1024 * 128 + 2 * 128 * 6)
+    assert fl["iqn_bwd_kernel"] == 2048 * 2 * 1024 * 320
+    assert abs(sum(fl.values()) / 1e9 - 2.97) < 0.02     # 2.97 GFLOP per c3 step
     assert b.FP32_MFMA_PEAK_TFLOPS == 157.3 and b.HBM_PEAK_GBS == 8000.0
