@@ -251,7 +251,7 @@ def main():
         traffic_all = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic_all = json.load(open(tpath)).get(f"c{args.config}", {})
+            traffic_all = json.load(open(tpath)).get(f"configs{args.config}", {})
         roof = None
         if kern:
             mf = [k for k in fl if kern.get(k)]

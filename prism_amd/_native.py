@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprism_hip.so")
+LIB_PATH = os.environ.get("PRISM_HIP_LIB") or os.path.join(_HERE, "libprism_hip.so")   # (override: kernel experiments)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "prism_hip.h")
 
 PRISM_OK = 0

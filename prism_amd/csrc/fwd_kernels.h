@@ -167,7 +167,9 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
         const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
         // first requests: everything the first column step needs, plus what the second one needs before
         // a refill of the first one's registers could land
-        f32x4 wphi0[4], wphi[4], w1[NHT], e4[2], b4[2];
+        // trunk weights: WD register sets, each refilled for column step nt + WD right after step nt used it
+        constexpr int WD = 1;      // (two steps in flight measured no faster: the loop is not load-latency-bound)
+        f32x4 wphi0[4], wphi[4], w1[WD][NHT], e4[2], b4[2];
         if (PHI) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) wphi0[q] = wp[q * 64];
@@ -177,10 +179,14 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
         e4[0] = *reinterpret_cast<gcf4>(erow);
         e4[1] = *reinterpret_cast<gcf4>(erow + 16);
 #pragma unroll
-        for (int ht = 0; ht < NHT; ++ht) w1[ht] = wp[(W0 + ht) * 64];
+        for (int ht = 0; ht < NHT; ++ht) w1[0][ht] = wp[(W0 + ht) * 64];
         if (PHI) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) wphi[q] = wp[(SL + q) * 64];
+        }
+        if (WD == 2) {
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) w1[WD - 1][ht] = wp[(SL + W0 + ht) * 64];
         }
         // the head Linear of the row phase (requested first of all): parked in LDS, read after the fold
 #pragma unroll
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
 #pragma unroll
         for (int nt = 0; nt < FW_NT; ++nt) {
             const bool more = nt + 1 < FW_NT;
+
             if (PHI && more) {
                 pacc = b4[(nt + 1) & 1];
                 if (nt + 3 < FW_NT) b4[(nt + 1) & 1] = *reinterpret_cast<gcf4>(brow + 16 * (nt + 3));
@@ -265,13 +272,13 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
                 for (int r = 0; r < 4; ++r) {
                     // phi steps carried by this (hp, r) slot: two while H = 128 (16 slots carry 16 + 16), one for H = 256
                     const int p0 = NHT == 8 ? (hp * 4 + r) * 2 : hp * 4 + r, p1 = NHT == 8 ? p0 + 1 : 16;
-                    accT[2 * hp] = mfma16(FW_SEL(w1[2 * hp], r), x[r], accT[2 * hp]);
+                    accT[2 * hp] = mfma16(FW_SEL(w1[nt % WD][2 * hp], r), x[r], accT[2 * hp]);
                     if (PHI && more && p0 < 16) {
                         pacc = mfma16(FW_SEL(wphi[p0 >> 2], p0 & 3), FW_SEL(cosB[p0 >> 2], p0 & 3), pacc);
                         if ((p0 & 3) == 3 && nt + 2 < FW_NT) wphi[p0 >> 2] = wp[((nt + 2) * SL + (p0 >> 2)) * 64];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    accT[2 * hp + 1] = mfma16(FW_SEL(w1[2 * hp + 1], r), x[r], accT[2 * hp + 1]);
+                    accT[2 * hp + 1] = mfma16(FW_SEL(w1[nt % WD][2 * hp + 1], r), x[r], accT[2 * hp + 1]);
                     if (PHI && more && p1 < 16) {
                         pacc = mfma16(FW_SEL(wphi[p1 >> 2], p1 & 3), FW_SEL(cosB[p1 >> 2], p1 & 3), pacc);
                         if ((p1 & 3) == 3 && nt + 2 < FW_NT) wphi[p1 >> 2] = wp[((nt + 2) * SL + (p1 >> 2)) * 64];
@@ -282,9 +289,9 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
                     if (more && hp == (PHI ? (NHT == 8 ? 2 : 4) : NHT / 2 - 1)) finish_x(xn, nt + 1, r);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (more) {
-                    w1[2 * hp] = wp[((nt + 1) * SL + W0 + 2 * hp) * 64];
-                    w1[2 * hp + 1] = wp[((nt + 1) * SL + W0 + 2 * hp + 1) * 64];
+                if (nt + WD < FW_NT) {
+                    w1[nt % WD][2 * hp] = wp[((nt + WD) * SL + W0 + 2 * hp) * 64];
+                    w1[nt % WD][2 * hp + 1] = wp[((nt + WD) * SL + W0 + 2 * hp + 1) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -482,8 +482,14 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
 #define BWD_CHUNKS 8
 #endif
 
-template <int H, bool LN>
-__global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
+// DB = true: ONE wave per SIMD (one workgroup per CU, twice the register budget): the workgroup's weight slices
+// live in registers, tiles are double-buffered -- every operand of tile i+1 is requested at the start of tile i --
+// and the wave feeds the matrix pipe on its own (three independent chains, VALU in the MFMA shadows).
+// DB = false: operands roll forward inside one register set (every set is refilled right after its last use), weight
+// slices are read from LDS; width 128: two workgroups per CU share each SIMD, width 256: one (the accumulators
+// alone take 80 registers; two tile sets do not fit).
+template <int H, bool LN, bool DB>
+__global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
     constexpr int NHT = H / 16, NU = H / 64, BWD_ACC = bwd_acc(H);
     constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);     // slab: phi_w | phi_b | [ln1_g | ln1_b] | w1
     typedef const f32x4 __attribute__((address_space(1))) *g4;
@@ -572,80 +578,105 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
 
     // ---- operands of a tile ---------------------------------------------------------------------
-    f32x4 ac[4], ad[NHT];             // row on the lane:   cos[r0 + j][16q + 4g ..], dpre1[r0 + j][16q + 4g ..]
-    f32x4 cB[4], dB[4][NU];           // row on the k index: cos[r0 + 4g + r][4j ..],  dpre1[r0 + 4g + r][64u + 4j ..]
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, c1 = mu, c2 = mu;
-    float ev = 0.f;
-    auto load_rows_a = [&](int ti) __attribute__((always_inline)) {
+    struct TileSet {
+        f32x4 ac[4], ad[NHT];             // row on the lane:   cos[r0 + j][16q + 4g ..], dpre1[r0 + j][16q + 4g ..]
+        f32x4 cB[4], dB[4][NU];           // row on the k index: cos[r0 + 4g + r][4j ..],  dpre1[r0 + 4g + r][64u + 4j ..]
+        f32x4 mu, rs, c1, c2;
+        float ev;
+    };
+    auto load_rows_a = [&](TileSet &S, int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = bload4(rs_cos, vo_ca + 64 * q, r0 * K_BASIS * 4);
+        for (int q = 0; q < 4; ++q) S.ac[q] = bload4(rs_cos, vo_ca + 64 * q, r0 * K_BASIS * 4);
 #pragma unroll
-        for (int q = 0; q < NHT; ++q) ad[q] = bload4(rs_dp, vo_da + 64 * q, r0 * H * 4);
+        for (int q = 0; q < NHT; ++q) S.ad[q] = bload4(rs_dp, vo_da + 64 * q, r0 * H * 4);
     };
-    auto load_rows_b = [&](int ti) __attribute__((always_inline)) {
+    auto load_rows_b = [&](TileSet &S, int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            cB[r] = bload4(rs_cos, vo_cb + r * K_BASIS * 4, r0 * K_BASIS * 4);
+            S.cB[r] = bload4(rs_cos, vo_cb + r * K_BASIS * 4, r0 * K_BASIS * 4);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) dB[r][u] = bload4(rs_dp, vo_db + r * H * 4 + 256 * u, r0 * H * 4);
+            for (int u = 0; u < NU; ++u) S.dB[r][u] = bload4(rs_dp, vo_db + r * H * 4 + 256 * u, r0 * H * 4);
         }
     };
-    auto load_scalars = [&](int ti) __attribute__((always_inline)) {
+    auto load_scalars = [&](TileSet &S, int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
         if (LN) {
-            mu = bload4(rs_mu, vo_sc, r0 * 4);
-            rs = bload4(rs_rs, vo_sc, r0 * 4);
-            c1 = bload4(rs_c1, vo_sc, r0 * 4);
-            c2 = bload4(rs_c2, vo_sc, r0 * 4);
+            S.mu = bload4(rs_mu, vo_sc, r0 * 4);
+            S.rs = bload4(rs_rs, vo_sc, r0 * 4);
+            S.c1 = bload4(rs_c1, vo_sc, r0 * 4);
+            S.c2 = bload4(rs_c2, vo_sc, r0 * 4);
         }
-        ev = e_cur[(int64_t)((r0 + 4 * g) / T) * E_DIM + n];
+        S.ev = e_cur[(int64_t)((r0 + 4 * g) / T) * E_DIM + n];
     };
+    TileSet S0, S1;
+    S0.mu = S0.c1 = S0.c2 = S1.mu = S1.c1 = S1.c2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    S0.rs = S1.rs = f32x4{1.f, 1.f, 1.f, 1.f};
     if (tiles_per_wave > 0) {
-        load_rows_a(0);
-        load_scalars(0);
-        load_rows_b(0);
+        load_rows_a(S0, 0);
+        load_scalars(S0, 0);
+        load_rows_b(S0, 0);
     }
     __syncthreads();          // weight slices (and every wave's observation rows) are in LDS
+    f32x4 wphr[4], w1r[NHT];  // DB: this lane's B operands of the phi / dX products, for the whole kernel
+    if (DB) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wphr[q] = wphil[q * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < NHT; ++q) w1r[q] = w1l[q * 64 + lane];
+    }
     PRISM_STAMP(9);
 
-    for (int ti = 0; ti < tiles_per_wave; ++ti) {
+    auto tile = [&](TileSet &S, TileSet &Sn, int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
         const bool more = ti + 1 < tiles_per_wave;
         const int bsm = (r0 + 4 * g) / T;
+        if (DB && more) {          // the whole next tile, a full tile ahead of its first use
+            load_rows_a(Sn, ti + 1);
+            load_scalars(Sn, ti + 1);
+            load_rows_b(Sn, ti + 1);
+        }
         // ---- phi columns and dX columns: three independent MFMA chains interleaved -------------------
         f32x4 aphi = {bphi, bphi, bphi, bphi}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NHT / 2; ++q) {
-            const f32x4 wa = w1l[(2 * q) * 64 + lane], wb = w1l[(2 * q + 1) * 64 + lane];
-            f32x4 wp = {0.f, 0.f, 0.f, 0.f};
-            if (q < 4) wp = wphil[(q & 3) * 64 + lane];
+            f32x4 wa, wb, wp = {0.f, 0.f, 0.f, 0.f};
+            if (DB) {
+                wa = w1r[2 * q];
+                wb = w1r[2 * q + 1];
+                if (q < 4) wp = wphr[q & 3];
+            } else {
+                wa = w1l[(2 * q) * 64 + lane];
+                wb = w1l[(2 * q + 1) * 64 + lane];
+                if (q < 4) wp = wphil[(q & 3) * 64 + lane];
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (q < 4) aphi = mfma16(ac[q & 3][c], wp[c], aphi);
-                adx = mfma16(ad[2 * q][c], wa[c], adx);
-                adx2 = mfma16(ad[2 * q + 1][c], wb[c], adx2);
+                if (q < 4) aphi = mfma16(S.ac[q & 3][c], wp[c], aphi);
+                adx = mfma16(S.ad[2 * q][c], wa[c], adx);
+                adx2 = mfma16(S.ad[2 * q + 1][c], wb[c], adx2);
             }
             if (q & 1) __builtin_amdgcn_sched_barrier(0);      // (bounds how many weight registers are in flight)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_rows_a(ti + 1);            // the row-on-lane registers are free: refill them for the next tile
+        if (!DB && more) load_rows_a(S, ti + 1);  // the row-on-lane registers are free: refill them for the next tile
         __builtin_amdgcn_sched_barrier(0);
         // ---- elementwise backward of row group r (column n), then the weight-gradient MFMAs of that group:
         // the VALU work of group r + 1 issues in the shadow of the MFMAs of group r
         float dep = 0.f;
         float xv = 0.f, dpp = 0.f;
+        const float ev = S.ev;
         auto elementwise = [&](int r) __attribute__((always_inline)) {
             const float phi = fmaxf(aphi[r], 0.f);          // (bias already in the accumulator)
             const float h0 = phi * ev;
-            const float xhat = LN ? (h0 - mu[r]) * rs[r] : h0;
+            const float xhat = LN ? (h0 - S.mu[r]) * S.rs[r] : h0;
             xv = LN ? xhat * g1 + be1 : h0;                 // trunk input (B operand of dW1)
             const float dX = adx[r] + adx2[r];
             s_dg += dX * xhat;
             s_db += dX;
-            const float dh0 = LN ? rs[r] * (dX * g1 - c1[r] * (1.0f / E_DIM) - xhat * (c2[r] * (1.0f / E_DIM))) : dX;
+            const float dh0 = LN ? S.rs[r] * (dX * g1 - S.c1[r] * (1.0f / E_DIM) - xhat * (S.c2[r] * (1.0f / E_DIM))) : dX;
             dep += dh0 * phi;
             dpp = (phi > 0.f) ? dh0 * ev : 0.f;
             s_dbphi += dpp;
@@ -656,18 +687,18 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
             const float xr = xv, dr = dpp;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) accWphi[c] = mfma16(dr, cB[r][c], accWphi[c]);
+            for (int c = 0; c < 4; ++c) accWphi[c] = mfma16(dr, S.cB[r][c], accWphi[c]);
             if (r < 3) elementwise(r + 1);
 #pragma unroll
             for (int u = 0; u < NU; ++u)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) accW1[4 * u + c] = mfma16(dB[r][u][c], xr, accW1[4 * u + c]);
+                for (int c = 0; c < 4; ++c) accW1[4 * u + c] = mfma16(S.dB[r][u][c], xr, accW1[4 * u + c]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool ev_pos = ev > 0.f;
-        if (more) {
-            load_rows_b(ti + 1);
-            load_scalars(ti + 1);
+        if (!DB && more) {
+            load_rows_b(S, ti + 1);
+            load_scalars(S, ti + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         // d e[b][n]: sum over the T rows of a sample
@@ -689,6 +720,14 @@ __global__ __launch_bounds__(256, H == 128 ? 2 : 1) void iqn_bwd_kernel(IqnArgs 
             }
         }
         if (n_mine) s_dcv[ti * 64 + lane] = dcv;
+    };
+    if (DB) {
+        for (int ti = 0; ti < tiles_per_wave; ti += 2) {
+            tile(S0, S1, ti);
+            if (ti + 1 < tiles_per_wave) tile(S1, S0, ti + 1);
+        }
+    } else {
+        for (int ti = 0; ti < tiles_per_wave; ++ti) tile(S0, S0, ti);
     }
     // ---- conv taps of (sample, channel cs>>2, output position (y0 + (j>>3), j&7)) for every tile of this wave;
     // LDS reads of this wave's own earlier writes need no barrier

@@ -153,7 +153,18 @@ struct Carver {
     }
 };
 
-static constexpr int N_CHUNKS = BWD_CHUNKS;
+// backward decomposition: one workgroup per CU with double-buffered tiles (4 row chunks x 64 column slices = 256
+// workgroups), or two workgroups per CU sharing each SIMD (8 row chunks; width 128 only).  Measured on MI355X
+// (configs[2]): 33.4 us vs 30.3 us -- one wave per SIMD cannot keep the matrix pipe fed through its own VALU and
+// hazard bubbles, the shared form is the default; PRISM_BWD_MODE=1 picks the first form for A/B runs.
+static constexpr int MAX_CHUNKS = 8;
+static int bwd_mode() {
+    static const int mode = [] { const char *e = getenv("PRISM_BWD_MODE"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+static bool bwd_double_buffered(int H) { return H == 128 && bwd_mode() != 0; }
+static int bwd_chunks(int H) { return (H == 128 && bwd_mode() == 0) ? 8 : 4; }      // workgroups per CU x 4
+
 
 static bool width_ok(int h) { return h == 128 || h == 256; }
 
@@ -222,10 +233,10 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.Db = c.f(B);
     w.lossw = c.f(B);
     w.de_iqn = c.f((size_t)B * E_DIM);
-    w.slabs = c.f((size_t)N_CHUNKS * iqn_slab_floats((int)Hi, ln));
+    w.slabs = c.f((size_t)MAX_CHUNKS * iqn_slab_floats((int)Hi, ln));
     {
         const size_t post_rows = (size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW;
-        const size_t bwd_rows = (size_t)(E_DIM / 16) * N_CHUNKS * BWD_CONV_ROW;
+        const size_t bwd_rows = (size_t)(E_DIM / 16) * MAX_CHUNKS * BWD_CONV_ROW;
         const size_t dqn_rows = d->head_layers == 1 && d->n_heads ? (size_t)B * CONV_ROW : 0;   // one row per sample
         const size_t m = post_rows > bwd_rows ? post_rows : bwd_rows;
         w.convpart = c.f(m > dqn_rows ? m : dqn_rows);
@@ -315,7 +326,8 @@ static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 
 
 static bool conv_in_bwd(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
-    return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, N_CHUNKS, iqn_width(d));
+    return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, bwd_chunks(iqn_width(d)),
+                       iqn_width(d));
 }
 
 static int post_block_count(const prism_learner_desc *ld) {
@@ -341,7 +353,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.ln = d.use_layer_norm;
     a.slab = iqn_slab_floats(a.Hi, a.ln);
     a.q_slab = q_slab_floats(a.Hq, a.ln);
-    a.n_chunks = N_CHUNKS;
+    a.n_chunks = bwd_chunks(a.Hi);
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
@@ -573,13 +585,21 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     }
     if (ld->dims.use_iqn) {
         ProfileScope ps_(K_BWD, stream);
+        const bool db = bwd_double_buffered(a.Hi);
         dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
             constexpr int HH = decltype(h)::value;
             constexpr bool LL = decltype(l)::value;
-            const size_t lds = (size_t)bwd_lds_floats(HH, B, a.C, a.T, N_CHUNKS, a.conv_in_bwd != 0) * sizeof(float);
-            herr = set_max_lds((const void *)iqn_bwd_kernel<HH, LL>, lds);
-            if (herr == hipSuccess)
-                hipLaunchKernelGGL((iqn_bwd_kernel<HH, LL>), dim3((E_DIM / 16) * N_CHUNKS), dim3(256), lds, stream, a);
+            const size_t lds = (size_t)bwd_lds_floats(HH, B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0) * sizeof(float);
+            const dim3 grid((E_DIM / 16) * a.n_chunks);
+            if constexpr (HH == 128) {
+                if (db) {
+                    herr = set_max_lds((const void *)iqn_bwd_kernel<HH, LL, true>, lds);
+                    if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd_kernel<HH, LL, true>), grid, dim3(256), lds, stream, a);
+                    return;
+                }
+            }
+            herr = set_max_lds((const void *)iqn_bwd_kernel<HH, LL, false>, lds);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd_kernel<HH, LL, false>), grid, dim3(256), lds, stream, a);
         });
         if (herr != hipSuccess) {
             set_error("hipFuncSetAttribute(iqn_bwd): %s", hipGetErrorString(herr));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the judged parts of a tools/profile_r01.sh run from gpurun_out/ into profiles/ and derive
+"""Copy the judged parts of a tools/profile.sh run from gpurun_out/ into profiles/ and derive
 per-launch HBM traffic (profiles/traffic.json) the way MI355X_MICROARCH.md prescribes:
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 — FETCH_SIZE reads half the bytes of wide coalesced
 reads on gfx950; both counters are in KiB and come from separate --pmc passes."""
@@ -11,7 +11,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, cfg = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "c2")
+# usage: summarize_profile.py <tag> [configs index]; files and traffic.json keys carry "configs<i>" = BASELINE.json configs[i]
+tag, cfg = sys.argv[1], "configs" + (sys.argv[2] if len(sys.argv) > 2 else "2")
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
