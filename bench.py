@@ -211,7 +211,7 @@ def main():
     # timed region: `repeats` blocks of EXACTLY `steps` steps each, every block bracketed by barrier + synchronize;
     # the reported rate is the median block (a 20-step block is 2 ms: one block alone is mostly noise)
     repeats = args.repeats if args.repeats > 0 else min(200, max(5, -(-2000 // max(1, args.steps))))
-    blocks = []
+    blocks, own_blocks = [], []
     for _ in range(repeats):
         sync()
         t0 = time.perf_counter()
@@ -219,12 +219,25 @@ def main():
             learner.step()
         sync()
         dt = time.perf_counter() - t0
+        own_blocks.append(dt)
         if world > 1:
             t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
         blocks.append(dt)
     elapsed = float(np.median(blocks))
+    dp_info = None
+    if world > 1:
+        # self-check of the data-parallel run: who took part, how the collective was launched, every rank's own rate
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, args.steps / float(np.median(own_blocks)))
+        dp_info = {"rccl_ranks": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                   "collective_in_graph": bool(getattr(agent, "collective_in_graph", False)),
+                   "graph_capture_fallback": getattr(agent, "_capture_error", None),
+                   "per_rank_steps_per_s": [round(float(x), 2) for x in per_rank],
+                   "replicas_identical": None}
+        from prism_amd.dist import assert_replicas_identical
+        dp_info["replicas_identical"] = bool(assert_replicas_identical(agent.flat if not rehearsal else agent.flat.cpu(), pg))
     # per-kernel durations: HIP events on the launch stream around every launch of `profile_steps` eager steps
     # (outside the timed blocks: the events cost ~2 us per launch)
     L.prism_profile_enable(1)
@@ -288,6 +301,8 @@ def main():
                           "replay_capacity_per_gpu": buf.capacity, "obs": "10x10x4 fp32", "n_actions": 6,
                           "parallelism": f"dp{world}", "hip_graph": any(isinstance(g, tuple) for g in getattr(agent, "_graphs", {}).values())},
                "roofline": roof}
+        if dp_info:
+            out["data_parallel"] = dp_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

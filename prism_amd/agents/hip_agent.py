@@ -194,6 +194,8 @@ class HipAgent:
                                          and getattr(config, "data_parallel", False)):
             self.world = torch.distributed.get_world_size(process_group)
         self._B = None
+        self.collective_in_graph = bool(getattr(config, "collective_in_graph", True))
+        self._capture_error = None
         self.model.train()
 
     # ------------------------------------------------------------------ descriptor
@@ -387,6 +389,23 @@ class HipAgent:
                 self._launch_fused(buf, d)
             g.replay()
             return (g,)
+        if self.collective_in_graph:
+            # data parallel, one graph: front + forward/backward, the RCCL all-reduce of the flat gradient, clip + Adam
+            # + writeback -- one launch per step, no host round trip around the collective.  The collective must have run
+            # once eagerly (communicator set up outside the capture): the warm step before this one did that.  Backends
+            # whose all-reduce cannot be captured (gloo: host staging) raise here; the step then falls back to two
+            # graphs around an eagerly launched collective, for good.
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._launch_fused(buf, d)
+                g.replay()
+                return (g,)
+            except Exception as e:          # noqa: BLE001 -- any capture failure selects the split form
+                self.collective_in_graph = False
+                self._capture_error = repr(e)
+                torch.cuda.synchronize()
+                # the failed capture ran nothing, but the step must still happen exactly once: fall through
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._launch_fused(buf, d, "front")
