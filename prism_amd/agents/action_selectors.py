@@ -31,7 +31,11 @@ class LinearAnneal:
 
 
 class ActionSelector:
-    def __init__(self):
+    """Instance attributes carry the reference's names (action_selectors.py:4-7,24-33,114-123): ``state.pkl`` pickles
+    these objects, and a checkpoint written here has to come back to life as the reference's classes (and vice versa)."""
+
+    def __init__(self, logger=None):
+        self.logger = logger
         self.loggables = {}
 
     def select_action(self, action_probs):
@@ -67,6 +71,18 @@ class EGreedyActionSelector(ActionSelector):
             return torch.nn.functional.one_hot(a, n_actions)
         return self.greedy.generate_action_probs(action_value_distribution, q_estimates)
 
+    def save(self, path):          # action_selectors.py:47-52
+        import os
+        with open(os.path.join(path, "epsilon.txt"), "w") as f:
+            f.write(str(self.epsilon.get_state()) + "\n")
+
+    def load(self, path):          # action_selectors.py:54-62
+        import os
+        eps_path = os.path.join(path, "epsilon.txt")
+        if os.path.exists(eps_path):
+            with open(eps_path) as f:
+                self.epsilon.set_state(int(f.readlines()[0]))
+
     def log(self, logger, action_value_distribution, q_estimates):
         logger.log_data(data=self.epsilon.get_value(), group_name="Report/Action Selector", var_name="Epsilon")
 
@@ -79,6 +95,7 @@ class IDSActionSelector(ActionSelector):
         super().__init__()
         self.lmbda, self.random_sample, self.epsilon = lmbda, random_sample, epsilon
         self.ids_rho_lower_bound, self.beta, self.unsquish_function = ids_rho_lower_bound, beta, unsquish_function
+        self.softmax = torch.nn.Softmax(dim=-1)
 
     def generate_action_probs(self, action_value_distribution, q_estimates, for_log=False):
         if self.unsquish_function is not None:
@@ -93,7 +110,7 @@ class IDSActionSelector(ActionSelector):
         gain = torch.log(1 + spread / rho) + self.epsilon
         scores = regret_sq / gain
         if self.random_sample:
-            probs = torch.softmax(-scores, dim=-1).clamp(min=self.epsilon, max=1)
+            probs = self.softmax(-scores).clamp(min=self.epsilon, max=1)
         else:
             probs = torch.nn.functional.one_hot(scores.argmin(dim=-1), scores.shape[-1])
         if for_log:

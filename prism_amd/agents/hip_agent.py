@@ -13,13 +13,13 @@ bit-identical.
 """
 import ctypes
 import os
-import pickle
 
 import numpy as np
 import torch
 
 from prism_amd import _native as N
 from prism_amd import dist as pdist
+from prism_amd.util import ref_pickle
 
 
 class HipAdam:
@@ -469,7 +469,7 @@ class HipAgent:
                  "eval_action_selector": self.eval_action_selector, "max_grad_norm": self.max_grad_norm,
                  "use_cuda_graph": self.use_cuda_graph}
         with open(os.path.join(path, "state.pkl"), "wb") as f:
-            pickle.dump(state, f)
+            ref_pickle.dump(state, f)          # class paths as the reference names them: it can load this file
 
     def load(self, directory):
         path = os.path.join(directory, "agent")
@@ -480,7 +480,8 @@ class HipAgent:
             self.target_model.load_state_dict(torch.load(os.path.join(path, "target_model.pt"),
                                                          map_location=self.device))
         with open(os.path.join(path, "state.pkl"), "rb") as f:
-            state = pickle.load(f)
+            state = ref_pickle.load(f)         # reference-written files name prism.agents.action_selectors.*
+        self._graphs = {}                      # captured graphs bake the hyper-parameters restored here
         self.action_selector = state["action_selector"]
         self.eval_action_selector = state["eval_action_selector"]
         self.max_grad_norm = state["max_grad_norm"]

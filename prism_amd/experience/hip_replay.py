@@ -12,6 +12,7 @@ batch layout without any host loop or H2D copy.
 """
 import ctypes
 import os
+import pickle
 import weakref
 
 import numpy as np
@@ -267,6 +268,22 @@ class HipReplayBuffer:
             return self._batch, info
         return self._batch
 
+    @torch.no_grad()
+    def gather(self, indices):
+        """The static batch for given slots: n-step return + collate (timestep_buffer.py:79-238) without sampling."""
+        self.flush()
+        idx = torch.as_tensor(indices).to(self.device, torch.int64).reshape(-1).contiguous()
+        B = int(idx.numel())
+        if self._index is None or self._index.shape[0] != B:
+            self._alloc_batch(B)
+        self._index.copy_(idx)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().prism_replay_gather(ctypes.byref(self._desc), N.ptr(self._index), B, N.ptr(self._obs),
+                                                N.ptr(self._next_obs), N.ptr(self._reward), N.ptr(self._nonterminal),
+                                                N.ptr(self._gamma), N.ptr(self._action), N.current_stream_handle()),
+                    "prism_replay_gather")
+        return self._batch
+
     def check_status(self):
         """Raise what torchrl would have raised at sample time (costs one D2H sync)."""
         bits = int(self.status.item())
@@ -311,10 +328,12 @@ class HipReplayBuffer:
                         "prism_replay_init")
 
     # ------------------------------------------------------------------ bulk fill (bench / restore)
-    def load_arrays(self, obs, succ_obs, reward, action, flags, link, priorities=None):
+    def load_arrays(self, obs, succ_obs, reward, action, flags, link, priorities=None, n_sampleable=None):
         """Fill the first n slots from device/host arrays and rebuild the trees from the given leaf
-        values (already (p+eps)**alpha).  Used for synthetic pre-fill and restore."""
+        values (already (p+eps)**alpha).  Used for synthetic pre-fill and restore.  ``n_sampleable`` < n: only the
+        first rows are stored items (sampled, counted by len()); the rest only serve as link targets."""
         n = int(obs.shape[0])
+        ns = n if n_sampleable is None else int(n_sampleable)
         if self._desc is None:
             self._allocate(tuple(obs.shape[1:]))
         O = self.obs_elems
@@ -328,35 +347,59 @@ class HipReplayBuffer:
         self.back.fill_(-1)
         valid = lk >= 0
         self.back[lk[valid].long()] = torch.arange(n, device=self.device, dtype=torch.int32)[valid]
-        self._size = n
-        self.buffer._writer._cursor = n % self.capacity
+        self._size = ns
+        self.buffer._writer._cursor = ns % self.capacity
         self._slot_id[:n] = np.arange(n)
         if self.use_per:
             tc = self.tree_capacity
-            p = torch.ones(n, device=self.device) if priorities is None else torch.as_tensor(priorities)
-            self.sum_tree[tc:tc + n].copy_(p)
-            self.min_tree[tc:tc + n].copy_(p)
+            p = torch.ones(ns, device=self.device) if priorities is None else torch.as_tensor(priorities)[:ns]
+            self.sum_tree[tc:tc + ns].copy_(p)
+            self.min_tree[tc:tc + ns].copy_(p)
             with torch.cuda.device(self.device):
                 N.check(N.lib().prism_per_rebuild(ctypes.byref(self._desc), N.current_stream_handle()),
                         "prism_per_rebuild")
 
     def save(self, path):
+        """``TimestepBuffer.save`` (timestep_buffer.py:259-296): ``experience_buffer/timesteps.pkl`` in the reference's
+        format (ref_format.py).  The reference also writes torchrl's sampler / writer dumps there -- third-party formats
+        that cannot be pinned; priorities, running maximum and the ring cursor go to ``hip_sampler.pt``."""
+        from prism_amd.experience import ref_format
         self.flush()
-        os.makedirs(os.path.join(path, "experience_buffer"), exist_ok=True)
+        d = os.path.join(path, "experience_buffer")
+        os.makedirs(d, exist_ok=True)
         n = self._size
-        state = dict(size=n, cursor=self.buffer._writer._cursor, obs=self.obs[:n].cpu(),
-                     succ_obs=self.succ_obs[:n].cpu(), reward=self.reward[:n].cpu(), action=self.action[:n].cpu(),
-                     flags=self.flags[:n].cpu(), link=self.link[:n].cpu(), per_state=self.per_state.cpu(),
-                     obs_shape=self._obs_shape)
+        flat = ref_format.serialize_ring(self.obs[:n].cpu().numpy(), self.succ_obs[:n].cpu().numpy(),
+                                         self.reward[:n].cpu().numpy(), self.action[:n].cpu().numpy(),
+                                         self.flags[:n].cpu().numpy(), self.link[:n].cpu().numpy(),
+                                         self.back[:n].cpu().numpy(), self._slot_id[:n], self._obs_shape)
+        with open(os.path.join(d, "timesteps.pkl"), "wb") as f:
+            pickle.dump(flat, f)
+        state = dict(size=n, cursor=self.buffer._writer._cursor, per_state=self.per_state.cpu())
         if self.use_per:
             tc = self.tree_capacity
             state["leaves"] = self.sum_tree[tc:tc + n].cpu()
-        torch.save(state, os.path.join(path, "experience_buffer", "hip_replay.pt"))
+        torch.save(state, os.path.join(d, "hip_sampler.pt"))
 
     def load(self, path):
-        st = torch.load(os.path.join(path, "experience_buffer", "hip_replay.pt"))
-        n = st["size"]
-        self.load_arrays(st["obs"].reshape((n,) + tuple(st["obs_shape"])), st["succ_obs"], st["reward"],
-                         st["action"], st["flags"], st["link"], st.get("leaves"))
-        self.per_state.copy_(st["per_state"])
-        self.buffer._writer._cursor = st["cursor"]
+        """``TimestepBuffer.load`` (timestep_buffer.py:298-318) of a file written here or by the reference; without
+        ``hip_sampler.pt`` (a reference-written directory) every slot starts at the default priority."""
+        from prism_amd.experience import ref_format
+        d = os.path.join(path, "experience_buffer")
+        with open(os.path.join(d, "timesteps.pkl"), "rb") as f:
+            flat = pickle.load(f)
+        r = ref_format.ring_from_timesteps(flat)
+        n, n_all = int(r["n_kept"]), min(int(r["obs"].shape[0]), self.capacity)
+        st = torch.load(os.path.join(d, "hip_sampler.pt")) if os.path.exists(os.path.join(d, "hip_sampler.pt")) else None
+        leaves = None
+        if st is not None and "leaves" in st and int(st["size"]) == n:
+            leaves = st["leaves"]
+        elif self.use_per:
+            smp = self.buffer._sampler
+            leaves = torch.full((n,), float(np.float32(np.float32(1.0 + smp._eps) ** np.float32(smp._alpha))))
+        link = np.where(r["link"][:n_all] < n_all, r["link"][:n_all], -1)
+        self.load_arrays(r["obs"][:n_all], r["succ_obs"][:n_all], r["reward"][:n_all], r["action"][:n_all], r["flags"][:n_all],
+                         link, leaves, n_sampleable=n)
+        self._slot_id[:n_all] = r["ids"][:n_all]
+        if st is not None:
+            self.per_state.copy_(st["per_state"])
+        self.buffer._writer._cursor = int(st["cursor"]) if st is not None else n % self.capacity

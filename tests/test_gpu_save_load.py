@@ -49,10 +49,15 @@ def test_replay_save_load_round_trip(tmp_path):
     new.load(str(tmp_path))
     torch.cuda.synchronize()
     assert len(new) == len(buf) == 26 and new.buffer._writer._cursor == buf.buffer._writer._cursor
-    for name in ("obs", "succ_obs", "reward", "action", "flags", "link", "back", "per_state"):
+    for name in ("obs", "succ_obs", "reward", "action", "link", "back", "per_state"):
         a, b = getattr(buf, name), getattr(new, name)
         n = min(a.shape[0], 26) if name != "per_state" else a.shape[0]
         assert torch.equal(a[:n].cpu(), b[:n].cpu()), name
+    # flags: the last stored step's successor had not been stored -> written truncated, exactly as the reference's
+    # save does (timestep_buffer.py:276-291: the collectors' state cannot be recovered); every other slot unchanged
+    f0, f1 = buf.flags[:26].cpu().numpy(), new.flags[:26].cpu().numpy()
+    np.testing.assert_array_equal(f0[:25], f1[:25])
+    assert f1[25] == f0[25] | 2 and (f0[25] & 4) and int(buf.link[25]) == -1
     assert torch.equal(buf.tree.cpu(), new.tree.cpu())          # every node, sum and min
     # the restored buffer samples what the original samples (same device RNG stream position)
     new._draws = buf._draws
@@ -94,3 +99,75 @@ def test_agent_save_load_round_trip(tmp_path, name):
     torch.cuda.synchronize()
     assert torch.equal(td0.cpu(), td1.cpu())
     assert torch.equal(agent.flat.cpu(), other.flat.cpu())
+
+
+def test_agent_loads_a_checkpoint_written_by_the_reference(tmp_path):
+    """tests/golden/ref_checkpoint was written by the reference's Agent.save (tools/gen_golden.py checkpoint)."""
+    import os
+    import shutil
+    dev = _need_gpu()
+    from prism_amd.agents import action_selectors as S
+    from prism_amd.config import MINATAR_CONFIG, derive
+    from prism_amd.factory import agent_factory
+    exp = np.load(os.path.join(H.GOLDEN, "ref_checkpoint_expected.npz"))
+    cfg = derive(MINATAR_CONFIG, device=dev, use_cuda_graph=False, use_ids=False, use_iqn=False, use_dqn=True,
+                 use_layer_norm=False, use_e_greedy=True, use_target_network=True, seed=999)     # other initial weights
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = agent_factory.build_agent(cfg, (10, 10, 4), 6)
+    agent.load(os.path.join(H.GOLDEN, "ref_checkpoint"))
+    sd = agent.model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in exp["param_names"]]
+    np.testing.assert_array_equal(np.array([float(v.cpu().double().sum()) for v in sd.values()]), exp["sum"])
+    np.testing.assert_array_equal(np.array([float(v.cpu().double().norm()) for v in sd.values()]), exp["l2"])
+    assert agent.n_updates == int(exp["n_updates"]) and agent.max_grad_norm == float(exp["max_grad_norm"])
+    assert int(agent.optimizer.step_t.item()) == int(exp["adam_step"])
+    off = 0
+    for i, n in enumerate(agent.optimizer.numels):
+        assert abs(float(agent.optimizer.exp_avg[off:off + n].cpu().double().norm()) - float(exp["exp_avg_l2"][i])) < 1e-12
+        off += n
+    assert isinstance(agent.action_selector, S.EGreedyActionSelector)
+    assert agent.action_selector.epsilon.get_state() == int(exp["epsilon_step"])
+    tgt = agent.target_model.state_dict()
+    assert all(torch.isfinite(v).all() for v in tgt.values())
+    # written back out, the directory has the reference's layout and its state.pkl names the reference's classes
+    agent.save(str(tmp_path))
+    names = sorted(os.listdir(tmp_path / "agent"))
+    assert names == ["model.pt", "optimizer.pt", "state.pkl", "target_model.pt"]
+    raw = open(tmp_path / "agent" / "state.pkl", "rb").read()
+    assert b"prism_amd" not in raw and b"cprism.agents.action_selectors\nEGreedyActionSelector\n" in raw
+    ref_sd = torch.load(os.path.join(H.GOLDEN, "ref_checkpoint", "agent", "model.pt"), map_location="cpu")
+    new_sd = torch.load(str(tmp_path / "agent" / "model.pt"), map_location="cpu")
+    for k in ref_sd:
+        assert torch.equal(ref_sd[k], new_sd[k]), k
+    shutil.rmtree(tmp_path / "agent")
+
+
+def test_replay_loads_a_buffer_file_written_by_the_reference():
+    """tests/golden/ref_buffer/experience_buffer/timesteps.pkl was written by the reference's TimestepBuffer.save; the
+    expected batch is what the reference collates from its OWN load of that file (tools/gen_golden.py nstep)."""
+    import os
+    dev = _need_gpu()
+    from prism_amd.experience import HipReplayBuffer
+    exp = np.load(os.path.join(H.GOLDEN, "ref_buffer_expected.npz"))
+    n = int(exp["n"])
+    buf = HipReplayBuffer(100, n, device=dev, n_step=3, gamma=0.99, use_per=True, alpha=0.5, beta=0.5, seed=1)
+    buf.load(os.path.join(H.GOLDEN, "ref_buffer"))
+    assert len(buf) == n
+    np.testing.assert_array_equal(buf._slot_id[:n], exp["ids"])
+    batch = buf.gather(torch.arange(n, device=dev))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(batch["observation"].cpu().numpy().reshape(exp["obs"].shape), exp["obs"])
+    import pickle
+    from prism_amd.experience import ref_format
+    from tests.test_ref_formats import check_next_obs
+    flat = pickle.load(open(os.path.join(H.GOLDEN, "ref_buffer", "experience_buffer", "timesteps.pkl"), "rb"))
+    check_next_obs(batch["next"]["observation"].cpu().numpy().reshape(n, -1), ref_format.ring_from_timesteps(flat),
+                   ref_format.parse_timesteps(flat), exp)
+    np.testing.assert_array_equal(batch["next"]["reward"].cpu().numpy(), exp["reward"])
+    np.testing.assert_array_equal(batch["nonterminal"].cpu().numpy(), exp["nonterminal"])
+    np.testing.assert_array_equal(batch["gamma"].cpu().numpy(), exp["gamma"])
+    np.testing.assert_array_equal(batch["action"].cpu().numpy(), exp["action"])
+    # every loaded slot starts at the sampler's default priority and can be sampled
+    b, info = buf.sample(return_info=True)
+    torch.cuda.synchronize()
+    assert int(info["index"].max()) < n and torch.all(info["_weight"] == 1.0)

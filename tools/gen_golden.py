@@ -282,14 +282,83 @@ def gen_nstep():
     print("nstep_chain:", N, "timesteps; needs_n_step:", int(out["exp_needs_n_step"].sum()),
           "terminal rows:", int((~out["exp_batch_nonterminal"]).sum()))
 
+    # ---- the same chain through the reference's buffer checkpoint: TimestepBuffer.save -> timesteps.pkl, then its
+    # own load and collate again (timestep_buffer.py:259-318).  The torchrl sampler / writer dumps are absent here:
+    # stand-ins that write nothing.
+    class Dumper:
+        def dumps(self, path):
+            pass
+
+        def loads(self, path):
+            pass
+
+    rb = FakeRB()
+    rb._storage = [[t] for t in stored]
+    rb._sampler, rb._writer = Dumper(), Dumper()
+    buf.buffer = rb
+    ck = os.path.join(OUT, "ref_buffer")
+    with contextlib.redirect_stdout(io.StringIO()):
+        buf.save(ck)
+        rb2 = FakeRB()
+        rb2._storage = [None] * N
+        rb2._sampler, rb2._writer = Dumper(), Dumper()
+        buf2 = TimestepBuffer(rb2, frame_stack=1, device="cpu", n_step=n_step, gamma=gamma)
+        buf2.load(ck)
+    kept = [s_[0] for s_ in rb2._storage if s_ is not None]
+    batch2 = buf2._timesteps_to_batch(kept, len(kept))
+    np.savez_compressed(os.path.join(OUT, "ref_buffer_expected.npz"), n=len(kept), ids=np.array([t.id for t in kept]),
+                        obs=batch2["observation"].numpy(), next_obs=batch2["next"]["observation"].numpy(),
+                        reward=batch2["next"]["reward"].numpy(), nonterminal=batch2["nonterminal"].numpy(),
+                        gamma=batch2["gamma"].numpy(), action=batch2["action"].numpy())
+    print("ref_buffer: saved", N, "timesteps, the reference's own load keeps", len(kept))
+
+
+def gen_checkpoint():
+    """A checkpoint directory written by the reference's Agent.save (agent.py:179-203) after two updates of a small
+    DQN agent with an epsilon-greedy selector, plus a state dict holding an IDS selector: files as the reference
+    wrote them (tensors + pickled selector objects)."""
+    import pickle
+    import shutil
+    from prism.config import Config, MINATAR_CONFIG
+    from prism.factory import agent_factory
+    from prism.agents.action_selectors import IDSActionSelector
+    cfg = Config(**MINATAR_CONFIG.__dict__)
+    cfg.device, cfg.use_cuda_graph = "cpu", False
+    for k, v in dict(use_ids=False, use_iqn=False, use_dqn=True, use_layer_norm=False, use_e_greedy=True,
+                     use_target_network=True).items():
+        setattr(cfg, k, v)
+    torch.manual_seed(cfg.seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = agent_factory.build_agent(cfg, (10, 10, 4), 6)
+    rng = np.random.default_rng(99)
+    for _ in range(2):
+        b = synth_batch(rng, 32)
+        agent.update(to_ref_batch(b), per_weights=torch.from_numpy(b["w"]))
+    agent.action_selector.epsilon.update(1234)
+    ck = os.path.join(OUT, "ref_checkpoint")
+    shutil.rmtree(ck, ignore_errors=True)
+    agent.save(ck)
+    names, s, l2 = tensor_stats(agent.model.state_dict())
+    opt = agent.optimizer.state_dict()
+    np.savez_compressed(os.path.join(OUT, "ref_checkpoint_expected.npz"), param_names=np.array(names), sum=s, l2=l2,
+                        n_updates=agent.n_updates, max_grad_norm=agent.max_grad_norm, epsilon_step=1234,
+                        adam_step=float(opt["state"][0]["step"]),
+                        exp_avg_l2=np.array([float(opt["state"][i]["exp_avg"].double().norm()) for i in range(len(names))]))
+    ids = IDSActionSelector(lmbda=0.1, random_sample=False, epsilon=1e-10, ids_rho_lower_bound=0.25, beta=0.8)
+    with open(os.path.join(ck, "state_ids.pkl"), "wb") as f:
+        pickle.dump({"action_selector": ids, "n_updates": 7}, f)
+    print("ref_checkpoint:", sorted(os.listdir(os.path.join(ck, "agent"))))
+
 
 def main():
     os.makedirs(OUT, exist_ok=True)
     _import_reference()
-    which = sys.argv[1:] or (list(CASES) + ["nstep", "config"])
+    which = sys.argv[1:] or (list(CASES) + ["nstep", "config", "checkpoint"])
     for name in which:
         if name == "nstep":
             gen_nstep()
+        elif name == "checkpoint":
+            gen_checkpoint()
         elif name == "config":
             gen_config_snapshot()
         else:
