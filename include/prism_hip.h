@@ -267,6 +267,28 @@ int prism_step_front(const prism_learner_desc *ld, const prism_replay_desc *rp, 
 int prism_step_back(const prism_learner_desc *ld, const prism_replay_desc *rp, const int64_t *index,
                     float alpha, float eps, prism_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Acting forward -- Agent.forward (prism/agents/agent.py:31-41): CompositeModel.forward(for_action=True)
+ * (composite_model.py:51-70; iqn_model.py:61-87 with n_quantile_samples_per_action rows per observation;
+ * q_ensemble.py:44-48) on the learner's parameters and workspace, with the same forward tiles as the update.
+ *   obs      [n][10][10][C], 1 <= n <= ld->batch (Q heads: the 16-padded n as well)
+ *   tau_in   [n_tau*n] tau-major (row = t*n + b, iqn_model.py:66-70) or NULL -> Philox(seed, offset)
+ *   out_z    [ceil16(n*n_tau)][A]  quantile estimates, SAMPLE-major (row = b*n_tau + t); reference layout =
+ *            view(n, n_tau, A).permute(1, 0, 2)
+ *   out_q    [heads][ceil16(n)][A] ensemble estimates; reference layout = [:, :n].permute(1, 2, 0)
+ * Either output may be NULL when the model has no such part. */
+int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n, int32_t n_tau,
+                      const float *tau_in, uint64_t seed, uint64_t offset, float *out_z, float *out_q,
+                      prism_stream_t stream);
+
+/* IDSActionSelector.generate_action_probs + select_action for ids_use_random_samples = False
+ * (prism/agents/action_selectors.py:125-176): scores [n][A] = regret^2 / information gain, action [n] = argmin.
+ * z / q: the buffers prism_act_forward filled.  out_aux (optional) [n][4][A]: ensemble mean, ensemble spread
+ * (torch.std), return-distribution variance, information gain -- what the selector logs. */
+int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
+                     int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
+                     float *out_aux, int64_t *out_action, prism_stream_t stream);
+
 /* Agent.sync_target_model (agent.py:149-152): target := online (device-to-device copy). */
 int prism_sync_target(float *target_params, const float *params, int64_t n_params,
                       prism_stream_t stream);

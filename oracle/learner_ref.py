@@ -16,6 +16,8 @@ Follows (paths under /root/reference):
   prism/agents/models/composite_model.py:94-144          batch unpack, td errors
   prism/agents/agent.py:53-79                            loss reduce, clip, optimizer step
   prism/factory/agent_factory.py:44-47                   Adam flags
+  prism/agents/models/composite_model.py:51-70           acting forward (act_forward)
+  prism/agents/action_selectors.py:125-176               IDS scores (ids_scores)
 Taus are explicit inputs, in the reference's draw order (iqn_model.py:104,112-126):
 current -> online-next (no target, or double-Q) -> target-next (target present).
 """
@@ -172,6 +174,34 @@ def qens_loss(p, p_tgt, spec, e_cur, e_next, acts, returns, dg):
         ratio = l2 / l2.mean()
         theil = (ratio * torch.log(ratio)).mean()
     return spec.q_loss_weight * (ql - theil * spec.theil_coef), theil
+
+
+def act_forward(p, spec, obs, taus):
+    """CompositeModel.forward(x, for_action=True) (composite_model.py:51-70): (q (n,A,heads), dist (T,n,A) or None).
+    taus (T*n,1) is the draw iqn_model.py:66-68 makes with T = n_quantile_samples_per_action."""
+    with torch.no_grad():
+        e = conv_embed(p, obs)
+        dist = None
+        if spec.use_iqn:
+            dist = iqn_forward(p, spec, e, taus).view(taus.shape[0] // e.shape[0], -1, spec.n_actions)
+        if spec.n_heads > 0:
+            q = qens_forward(p, spec, e)
+        else:
+            q = dist.mean(dim=0).unsqueeze(-1)
+    return q, dist
+
+
+def ids_scores(dist, q, lmbda, epsilon, rho_lower_bound):
+    """IDSActionSelector.generate_action_probs without random sampling (action_selectors.py:125-176):
+    dict of the logged intermediates + the chosen action."""
+    mean, variance = q.mean(dim=-1), q.std(dim=-1)
+    std = torch.sqrt(variance)
+    regret = torch.max(mean + lmbda * std, dim=-1).values.view(-1, 1) - (mean - lmbda * std)
+    var_z = dist.var(dim=0)
+    rho = torch.clamp(var_z / (epsilon + var_z.mean(dim=-1).unsqueeze(-1)), min=rho_lower_bound)
+    gain = torch.log(1 + variance / rho) + epsilon
+    scores = torch.square(regret) / gain
+    return dict(mean=mean, variance=variance, var_z=var_z, gain=gain, scores=scores, action=torch.argmin(scores, dim=-1))
 
 
 def _head_keys(p, h):

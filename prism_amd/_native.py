@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRISM_HIP_LIB") or os.path.join(_HERE, "libprism_hip.so")   # (override: kernel experiments)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "prism_hip.h")
 
-PRISM_OK = 0
+PRISM_OK, PRISM_ERR_INVALID, PRISM_ERR_HIP, PRISM_ERR_UNSUPPORTED = 0, -1, -2, -3
 PRISM_MAX_NSTEP = 15
 FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 STATUS_NONPOSITIVE_PSUM, STATUS_NONPOSITIVE_PMIN = 1, 2
@@ -91,6 +91,9 @@ SIGNATURES = {
     "prism_step_front": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_i64, c_vp, c_u64, c_u64, c_f32, c_vp, c_vp,
                                          c_vp]),
     "prism_step_back": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_vp, c_f32, c_f32, c_vp]),
+    "prism_act_forward": (ctypes.c_int, [_P(LearnerDesc), c_vp, c_i32, c_i32, c_vp, c_u64, c_u64, c_vp, c_vp, c_vp]),
+    "prism_ids_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp,
+                                        c_vp, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),

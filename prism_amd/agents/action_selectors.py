@@ -104,9 +104,11 @@ class IDSActionSelector(ActionSelector):
         mean, spread = q_estimates.mean(dim=-1), q_estimates.std(dim=-1)
         sd = spread.sqrt()
         upper = (mean + self.lmbda * sd).max(dim=-1).values.view(-1, 1)
-        regret_sq = (upper - (mean - self.lmbda * sd)).square()
+        regret = upper - (mean - self.lmbda * sd)
+        regret_sq = regret.square()
         var_z = action_value_distribution.var(dim=0)
-        rho = (var_z / (self.epsilon + var_z.mean(dim=-1, keepdim=True))).clamp(min=self.ids_rho_lower_bound)
+        normalized_var_z = var_z / (self.epsilon + var_z.mean(dim=-1, keepdim=True))
+        rho = normalized_var_z.clamp(min=self.ids_rho_lower_bound)
         gain = torch.log(1 + spread / rho) + self.epsilon
         scores = regret_sq / gain
         if self.random_sample:
@@ -114,9 +116,10 @@ class IDSActionSelector(ActionSelector):
         else:
             probs = torch.nn.functional.one_hot(scores.argmin(dim=-1), scores.shape[-1])
         if for_log:
-            self.loggables = {"Q Estimate Ensemble Mean": mean, "Q Estimate Ensemble Variance": spread,
-                              "Return Distribution Variance": var_z, "Information Gain": gain,
-                              "IDS Scores": scores, "Action Probs": probs}
+            self.loggables = {"Action Regret": regret, "Q Estimate Ensemble Mean": mean,
+                              "Q Estimate Ensemble Variance": spread, "Return Distribution Variance": var_z,
+                              "Information Gain": gain, "IDS Scores": scores, "Action Probs": probs,
+                              "Normalized Return Distribution Variance": normalized_var_z}
         return probs
 
     def select_action(self, action_probs):

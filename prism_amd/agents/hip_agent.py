@@ -188,6 +188,8 @@ class HipAgent:
         self.seed = int(config.seed)
         self._draw_offset = 0      # tau counters consumed by update() (host-issued offsets)
         self._fused_tau = 0        # ... and by fused steps (device counter, mirrored: one counter space for both paths)
+        self._act_draws = 0        # acting draws: a Philox stream of their own (key 3), counted separately
+        self._act_raw = None
         self.pg = process_group
         self.world = 1
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -424,10 +426,76 @@ class HipAgent:
             pdist.allreduce_grads(self.grads, self.pg)
             g[1].replay()
 
+    # ------------------------------------------------------------------ acting
+    @torch.no_grad()
+    def act_estimates(self, obs, taus=None):
+        """``(q_estimates, return_distribution)`` as ``CompositeModel.forward(x, for_action=True)`` hands them to the
+        action selector (composite_model.py:51-70): ``(n, A, heads)`` and ``(n_quantile_samples_per_action, n, A)``,
+        computed by the HIP forward tiles (``prism_act_forward``) on the learner's flat parameters.  ``taus``: explicit
+        quantile samples ``[T*n, 1]`` in the reference's order (parity tests).  The single-Linear DQN head
+        (``dqn_n_model_layers`` 0) has no tile form; its ``n x 1024 x A`` product stays a torch matmul on the device."""
+        from prism_amd.agents.modules import _as_tensor
+        obs = _as_tensor(obs, self.device).contiguous()
+        dm = self.dims
+        q_tiles = dm.n_heads > 0 and dm.head_layers == 2
+        if not dm.use_iqn and not q_tiles:
+            return self.model(obs, for_action=True)
+        if self._B is None:
+            self._prepare(int(self.config.batch_size))
+        n, B, A = int(obs.shape[0]), self._B, dm.n_actions
+        cap = (B // 16) * 16 if q_tiles else B
+        if cap < 1:
+            raise ValueError(f"acting through the Q-head tiles needs a learner batch of at least 16 (batch {B})")
+        if n > cap:          # more observations than the learner's workspace holds at once: in pieces
+            parts = [self.act_estimates(obs[i:i + cap], None if taus is None else
+                                        taus.view(-1, n)[:, i:i + cap].reshape(-1, 1)) for i in range(0, n, cap)]
+            q = torch.cat([p[0] for p in parts], dim=0) if parts[0][0] is not None else None
+            dist = torch.cat([p[1] for p in parts], dim=1) if parts[0][1] is not None else None
+            return q, dist
+        T = int(self.model.distribution_model.n_quantile_samples_per_action) if dm.use_iqn else 0
+        n_pad = (n + 15) // 16 * 16
+        z = torch.empty(((n * T + 15) // 16 * 16, A), device=self.device) if dm.use_iqn else None
+        qb = torch.empty((dm.n_heads, n_pad, A), device=self.device) if q_tiles else None
+        if taus is None and dm.use_iqn and self.tau_rng == "torch":
+            taus = torch.rand([T * n, 1], device=self.device)
+        tau = None if taus is None else taus.to(self.device, torch.float32).reshape(-1).contiguous()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().prism_act_forward(ctypes.byref(self._desc), N.ptr(obs), n, T, N.ptr(tau) if tau is not None else None,
+                                              self.seed, self._act_draws, N.ptr(z) if z is not None else None,
+                                              N.ptr(qb) if qb is not None else None, N.current_stream_handle()),
+                    "prism_act_forward")
+        self._act_draws += T * n
+        self._act_raw = (z, qb, n, n_pad, T)
+        dist = z[:n * T].view(n, T, A).permute(1, 0, 2) if z is not None else None
+        if qb is not None:
+            q = qb[:, :n].permute(1, 2, 0)
+        elif self.model.q_function_model is not None:
+            q = self.model.q_function_model(self.model.embedding_model(obs))
+        else:
+            q = dist.mean(dim=0).unsqueeze(-1)
+        return q, dist
+
     @torch.no_grad()
     def forward(self, obs):
-        q, dist = self.model(obs, for_action=True)
+        """Agent.forward (agent.py:31-41).  Deterministic information-directed sampling is scored and arg-minned by
+        ``prism_ids_select``; every other selector reads the two small estimate tensors with its own torch code."""
         sel = self.eval_action_selector if self._is_eval else self.action_selector
+        self._act_raw = None
+        q, dist = self.act_estimates(obs)
+        raw = self._act_raw
+        from prism_amd.agents.action_selectors import IDSActionSelector
+        if (type(sel) is IDSActionSelector and not sel.random_sample and sel.unsquish_function is None
+                and raw is not None and raw[0] is not None and raw[1] is not None):
+            z, qb, n, n_pad, T = raw
+            A = self.dims.n_actions
+            scores = torch.empty((n, A), device=self.device)
+            action = torch.empty(n, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, float(sel.lmbda),
+                                                 float(sel.epsilon), float(sel.ids_rho_lower_bound), N.ptr(scores), None,
+                                                 N.ptr(action), N.current_stream_handle()), "prism_ids_select")
+            self._act_scores = scores
+            return action
         return sel.select_action(sel.generate_action_probs(dist, q))
 
     @torch.no_grad()

@@ -1,0 +1,83 @@
+// Acting-time pieces: the information-directed-sampling score of every action
+// (/root/reference/prism/agents/action_selectors.py:125-176) from the quantile estimates Z [n][T][A] and the
+// ensemble estimates Q [heads][n_pad][A] the forward tiles leave behind (fwd_kernels.h, kinds 0 and 1).
+// One wave per observation: lanes split the T quantile samples; per action two passes (mean, then squared
+// deviations) as torch.var / torch.std do, unbiased (n - 1).
+#pragma once
+#include "common.h"
+
+namespace prism {
+
+struct IdsArgs {
+    const float *z;      // [n][T][A] sample-major quantile estimates
+    const float *q;      // [heads][n_pad][A]
+    int n, n_pad, T, A, heads;
+    float lmbda, eps, rho_lb;
+    float *scores;       // [n][A] IDS scores (regret^2 / information gain)
+    float *aux;          // [n][4][A]: ensemble mean | ensemble "variance" (torch.std) | return-distribution variance | information gain
+    int64_t *action;     // [n] argmin of the scores (first minimum)
+};
+
+__global__ __launch_bounds__(64) void ids_score_kernel(IdsArgs k) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int A = k.A, T = k.T, Hd = k.heads;
+    // ensemble statistics: lane = action
+    float mean = 0.f, spread = 0.f;
+    if (lane < A) {
+        float s = 0.f;
+        for (int h = 0; h < Hd; ++h) s += k.q[((int64_t)h * k.n_pad + b) * A + lane];
+        mean = s / (float)Hd;
+        float v = 0.f;
+        for (int h = 0; h < Hd; ++h) {
+            const float d = k.q[((int64_t)h * k.n_pad + b) * A + lane] - mean;
+            v += d * d;
+        }
+        spread = sqrtf(v / (float)(Hd > 1 ? Hd - 1 : 1));          // q_estimates.std(dim=-1): called "variance" there
+    }
+    const float sd = sqrtf(spread);                                 // torch.sqrt(variance)
+    const float hi = lane < A ? mean + k.lmbda * sd : -INFINITY;
+    const float upper = wave_max(hi);
+    const float regret = upper - (mean - k.lmbda * sd);
+    const float regret_sq = regret * regret;
+    // return-distribution variance per action over the T quantile samples (unbiased)
+    float var_mine = 0.f;
+    for (int a = 0; a < A; ++a) {
+        float s = 0.f;
+        for (int t = lane; t < T; t += 64) s += k.z[((int64_t)b * T + t) * A + a];
+        const float m = wave_sum(s) / (float)T;
+        float v = 0.f;
+        for (int t = lane; t < T; t += 64) {
+            const float d = k.z[((int64_t)b * T + t) * A + a] - m;
+            v += d * d;
+        }
+        const float var = wave_sum(v) / (float)(T > 1 ? T - 1 : 1);
+        if (lane == a) var_mine = var;
+    }
+    const float var_mean = wave_sum(lane < A ? var_mine : 0.f) / (float)A;
+    const float rho = fmaxf(var_mine / (k.eps + var_mean), k.rho_lb);
+    const float gain = logf(1.0f + spread / rho) + k.eps;
+    const float score = regret_sq / gain;
+    if (lane < A) {
+        k.scores[(int64_t)b * A + lane] = score;
+        if (k.aux) {
+            float *x = k.aux + (int64_t)b * 4 * A;
+            x[lane] = mean;
+            x[A + lane] = spread;
+            x[2 * A + lane] = var_mine;
+            x[3 * A + lane] = gain;
+        }
+    }
+    // argmin, first minimum wins (torch.argmin)
+    int best = 0;
+    float bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), 0));
+    for (int a = 1; a < A; ++a) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(score), a));
+        if (v < bv) {
+            bv = v;
+            best = a;
+        }
+    }
+    if (lane == 0) k.action[b] = best;
+}
+
+}  // namespace prism

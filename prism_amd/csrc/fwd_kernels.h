@@ -113,9 +113,11 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
             r.t = 0;
             r.save = ps_save ? (int64_t)hd * B + r.b : -1;
         } else if (kind == 0) {
+            // (T need not be a power of two here: the acting forward runs 200 quantile samples per observation, and its
+            // last tile may run past the last row: such rows compute on the last sample's data and land in padding)
             const int row = tile * 16 + m;
-            r.b = row >> tsh;
-            r.t = row & (T - 1);
+            r.b = min((T & (T - 1)) == 0 ? row >> tsh : row / T, B - 1);
+            r.t = row - r.b * T;
             r.save = ps_save ? (int64_t)row : -1;
         } else {
             const int s = m >> (tsh + 1), j = m & (2 * T - 1);
@@ -203,14 +205,14 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
                 const gcf tin = tau_src;
                 float tau;
                 if (tin) {
-                    tau = tin[(int64_t)r.t * B + r.b];
+                    tau = tin[min((int64_t)r.t, (int64_t)T - 1) * a.Bt + r.b];
                 } else {
                     uint32_t rr[4];
                     Philox ph(a.seed);
-                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * B + r.b), 0x54415530ull + (uint64_t)sid, rr);
+                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
                     tau = u32_to_unit_float(rr[0]);
                 }
-                if (a.tau_out) a.tau_out[(int64_t)sid * a.maxT * B + (int64_t)r.t * B + r.b] = tau;
+                if (a.tau_out && r.t < T) a.tau_out[(int64_t)sid * a.maxT * a.Bt + (int64_t)r.t * a.Bt + r.b] = tau;
                 rowf[tid] = tau;
             }
             lds_barrier();
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
             zt[fm * FW_ZS + fc] = zmine;
             // quantile / Q estimates of the row (also what the stand-alone loss kernels read)
             const gf zo = (kind == 2 && frow.nx) ? ps_z_out2 : ps_z_out;
-            const int64_t zr = kind == 1 ? (int64_t)hd * B + frow.b : (int64_t)frow.b * T + frow.t;
+            const int64_t zr = kind == 1 ? (int64_t)hd * B + frow.b : (int64_t)frow.b * T + frow.t;      // (kind 0: == row)
             zo[zr * A + fc] = zmine;
         }
     }

@@ -84,6 +84,7 @@ struct IqnArgs {
     IqnPass pass[6];
     int n_pass;
     int B, A, C, T, Tn;
+    int Bt;                // row stride of the tau-major quantile-sample arrays (== B except in the acting forward)
     int Hi, Hq;            // hidden width of the IQN trunk / of the Q heads
     int ln;                // use_layer_norm
     int slab, q_slab;      // floats per gradient slab

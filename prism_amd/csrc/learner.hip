@@ -13,6 +13,7 @@
 
 #include "step_kernels.h"
 #include "fwd_kernels.h"
+#include "act_kernels.h"
 
 namespace prism {
 
@@ -344,6 +345,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     float *tau_buf = nullptr, *dl_buf = nullptr;
     carve_iqn(&d, B, ld->workspace, &a.ws, &tau_buf, &dl_buf);
     a.B = B;
+    a.Bt = B;
     a.A = d.n_actions;
     a.C = d.in_channels;
     a.T = d.n_tau;
@@ -650,6 +652,105 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         (void)hipMemcpyAsync(ld->dbg_z, a.ws.zcur, R * A * 4, hipMemcpyDeviceToDevice, stream);
         (void)hipMemcpyAsync(ld->dbg_z + R * A, a.ws.ztg, Rn * A * 4, hipMemcpyDeviceToDevice, stream);
     }
+    return PRISM_OK;
+}
+
+// Acting forward (agent.py:31-41 -> composite_model.py:51-70, iqn_model.py:61-87 with for_action=True): embeds `n`
+// observations, runs n_tau quantile rows per observation through the IQN tiles and the observations through every
+// Q head -- the same forward tiles as the update, on the learner's workspace (the stream-packed weights are rebuilt
+// first: the last Adam step left them stale).
+extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n, int32_t n_tau,
+                                 const float *tau_in, uint64_t seed, uint64_t offset, float *out_z, float *out_q,
+                                 prism_stream_t stream_) {
+    int rc = check_learner(ld);
+    if (rc) return rc;
+    PRISM_CHECK_ARG(obs != nullptr && n >= 1 && n <= ld->batch, "n must be in [1, batch]");
+    const int n_pad = (n + 15) / 16 * 16;
+    PRISM_CHECK_ARG(n_pad <= ld->batch || ld->dims.n_heads == 0 || ld->dims.head_layers != 2,
+                    "Q-head tiles need the workspace of a batch >= 16-padded n");
+    PRISM_CHECK_ARG(!ld->dims.use_iqn || (n_tau >= 1 && out_z), "quantile samples per action / output buffer");
+    PRISM_CHECK_ARG(!(ld->dims.n_heads && ld->dims.head_layers == 2) || out_q, "Q output buffer");
+    hipStream_t stream = (hipStream_t)stream_;
+    IqnArgs a;
+    fill_iqn_args(ld, a);
+    hipError_t herr = hipSuccess;
+    // embed (+ the parameter-only roles): the n observations stand in for both batch halves
+    a.B = n;
+    a.obs = a.next_obs = obs;
+    hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * n + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a);
+    PRISM_CHECK_LAUNCH();
+    a.B = n_pad;
+    a.Bt = n;
+    a.seed = seed;
+    a.offset = offset;
+    a.rng = nullptr;
+    a.tau_out = nullptr;
+    a.local_loss = 0;
+    int np = 0, n_iqn = 0, n_q = 0;
+    IqnPass p;
+    if (ld->dims.use_iqn) {
+        memset(&p, 0, sizeof(p));
+        p.params = ld->params;
+        p.wpk = a.ws.wpk[0];
+        p.uv = a.ws.uv;
+        p.e = a.ws.e_cur;
+        p.tau_in = tau_in;
+        p.z_out = out_z;
+        p.T = n_tau;
+        p.n_tiles = n_iqn = (n * n_tau + 15) / 16;
+        p.kind = 0;
+        p.stream_id = 3;                 // a Philox stream of its own: acting draws never repeat an update's
+        a.pass[np++] = p;
+    }
+    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2) {
+        memset(&p, 0, sizeof(p));
+        p.params = ld->params;
+        p.wpk = a.ws.q_wpk[0];
+        p.uv = a.ws.q_uv;
+        p.e = a.ws.e_cur;
+        p.z_out = out_q;
+        p.T = 1;
+        p.n_tiles = n_q = (n_pad / 16) * ld->dims.n_heads;
+        p.kind = 1;
+        a.pass[np++] = p;
+    }
+    PRISM_CHECK_ARG(np > 0, "nothing to run: the single-Linear DQN head has no tile form (use the module forward)");
+    auto launch = [&](const IqnArgs &aa, int H, int tiles) {
+        dispatch_hl(H, aa.ln, [&](auto h, auto l) {
+            constexpr int HH = decltype(h)::value;
+            constexpr bool LL = decltype(l)::value;
+            const size_t lds = fw_lds_floats<HH>() * sizeof(float);
+            herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
+            if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(512), lds, stream, aa);
+        });
+    };
+    a.n_pass = np;
+    if (n_iqn && n_q && a.Hi != a.Hq) {
+        IqnArgs a1 = a, a2 = a;
+        a1.n_pass = a2.n_pass = 1;
+        a2.pass[0] = a.pass[1];
+        launch(a1, a.Hi, n_iqn);
+        launch(a2, a.Hq, n_q);
+    } else {
+        launch(a, n_iqn ? a.Hi : a.Hq, n_iqn + n_q);
+    }
+    if (herr != hipSuccess) {
+        set_error("hipFuncSetAttribute(fwd_tile): %s", hipGetErrorString(herr));
+        return PRISM_ERR_HIP;
+    }
+    PRISM_CHECK_LAUNCH();
+    return PRISM_OK;
+}
+
+// IDSActionSelector.generate_action_probs + select_action without random sampling (action_selectors.py:125-176).
+extern "C" int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
+                                int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
+                                float *out_aux, int64_t *out_action, prism_stream_t stream_) {
+    PRISM_CHECK_ARG(z && q && out_scores && out_action, "null buffers");
+    PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_tau >= 1 && n_actions >= 1 && n_actions <= 16 && n_heads >= 1, "bad sizes");
+    IdsArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, lmbda, epsilon, rho_lower_bound, out_scores, out_aux, out_action};
+    hipLaunchKernelGGL(ids_score_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream_, k);
+    PRISM_CHECK_LAUNCH();
     return PRISM_OK;
 }
 

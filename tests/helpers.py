@@ -88,3 +88,11 @@ def checksums(sd):
     s = np.array([float(v.double().sum()) for v in sd.values()])
     l2 = np.array([float(v.double().norm()) for v in sd.values()])
     return s, l2
+
+
+def case_act(g):
+    """Acting inputs / the reference's outputs of an update fixture: (obs (n,10,10,C), taus (T*n,1) or None, dict)."""
+    n, C = int(g["act/n"]), int(g["C"])
+    obs = np.unpackbits(g["act/obs_bits"])[:n * 100 * C].reshape(n, 10, 10, C).astype(np.float32)
+    taus = torch.from_numpy(g["act/tau"]).reshape(-1, 1) if "act/tau" in g.files else None
+    return torch.from_numpy(obs), taus, {k[4:]: g[k] for k in g.files if k.startswith("act/")}

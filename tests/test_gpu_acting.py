@@ -1,0 +1,147 @@
+"""GPU parity of the acting path: ``Agent.forward`` = CompositeModel.forward(for_action=True) +
+the action selector, run by ``prism_act_forward`` / ``prism_ids_select`` on the weights the golden update steps left
+behind, against the live reference's recorded outputs (tests/golden/update_*.npz, ``act/*``) and the CPU oracle.
+
+Tolerance (fp32): estimates within 1e-5 of the reference's; IDS scores within 1e-3 relative (a ratio of a squared
+regret and a logarithm of variances: each factor carries the estimates' 1e-6 relative error several times over);
+the chosen actions equal."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_gpu_learner import IQN_CASES, build_hip_agent, to_hip_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return "cuda:0"
+
+
+def updated_agent(name, dev):
+    g = H.load_case(name)
+    cfg, agent = build_hip_agent(g, dev)
+    for step in range(int(g["steps"])):
+        batch, w, taus = H.case_batch(g, step)
+        agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev), taus=[t.to(dev) for t in taus])
+        if cfg.use_target_network and step == 0:
+            agent.sync_target_model()
+    return g, cfg, agent
+
+
+@pytest.mark.parametrize("name", IQN_CASES)
+def test_acting_matches_reference(dev, name):
+    g, cfg, agent = updated_agent(name, dev)
+    obs, taus, ref = H.case_act(g)
+    q, dist = agent.act_estimates(obs.to(dev), taus=None if taus is None else taus.to(dev))
+    torch.cuda.synchronize()
+    assert tuple(q.shape) == ref["q"].shape
+    np.testing.assert_allclose(q.cpu().numpy(), ref["q"], rtol=0, atol=TOL)
+    if "dist" in ref:
+        assert tuple(dist.shape) == ref["dist"].shape
+        np.testing.assert_allclose(dist.cpu().numpy(), ref["dist"], rtol=0, atol=TOL)
+    else:
+        assert dist is None
+    # the selector on these estimates: the reference's choice
+    sel = agent.action_selector
+    probs = sel.generate_action_probs(dist, q)
+    np.testing.assert_array_equal(sel.select_action(probs).cpu().numpy(), ref["action"])
+    if cfg.use_ids:
+        # the fused scoring kernel, on the buffers the forward left on the device
+        z, qb, n, n_pad, T = agent._act_raw
+        from prism_amd import _native as N
+        A = int(g["A"])
+        scores = torch.empty((n, A), device=dev)
+        aux = torch.empty((n, 4, A), device=dev)
+        action = torch.empty(n, dtype=torch.int64, device=dev)
+        N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, cfg.ids_n_q_heads, cfg.ids_lambda,
+                                         cfg.ids_epsilon, cfg.ids_rho_lower_bound, N.ptr(scores), N.ptr(aux), N.ptr(action),
+                                         N.current_stream_handle()), "prism_ids_select")
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(action.cpu().numpy(), ref["action"])
+        np.testing.assert_allclose(scores.cpu().numpy(), ref["ids/IDS Scores"], rtol=1e-3, atol=1e-6)
+        a = aux.cpu().numpy()
+        np.testing.assert_allclose(a[:, 0], ref["ids/Q Estimate Ensemble Mean"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(a[:, 1], ref["ids/Q Estimate Ensemble Variance"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(a[:, 2], ref["ids/Return Distribution Variance"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(a[:, 3], ref["ids/Information Gain"], rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["full_small", "abl_ids", "iqn_c3"])
+def test_agent_forward_in_pieces_and_with_device_draws(dev, name):
+    """Agent.forward end to end (in-kernel Philox quantile samples): more observations than fit the workspace at once
+    are served in pieces; the same counter gives the same estimates; every action is a valid index and agrees with
+    the torch selector run on the same estimates."""
+    from oracle.learner_ref import act_forward
+    g, cfg, agent = updated_agent(name, dev)
+    C, A = int(g["C"]), int(g["A"])
+    rng = np.random.default_rng(5)
+    n = int(g["B"]) + 7
+    obs = torch.from_numpy((rng.random((n, 10, 10, C)) < 0.1).astype(np.float32)).to(dev)
+    T = cfg.iqn_quantile_samples_per_action
+    taus = torch.from_numpy(rng.random((T * n, 1)).astype(np.float32))
+    q, dist = agent.act_estimates(obs, taus=taus.to(dev))
+    sd = {k: v.cpu() for k, v in agent.model.state_dict().items()}
+    qo, do = act_forward(sd, H.spec_from_config(H.case_config(g), C=C, A=A), obs.cpu(), taus)
+    np.testing.assert_allclose(q.cpu().numpy(), qo.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(dist.cpu().numpy(), do.numpy(), rtol=0, atol=TOL)
+    # device draws: reproducible from the counter, uniform, and a new draw each call
+    agent._act_draws = 1000
+    q1, d1 = agent.act_estimates(obs[:5])
+    agent._act_draws = 1000
+    q2, d2 = agent.act_estimates(obs[:5])
+    assert torch.equal(d1, d2) and torch.equal(q1, q2)
+    q3, d3 = agent.act_estimates(obs[:5])
+    assert not torch.equal(d1, d3)
+    if cfg.use_ids:
+        assert torch.equal(q1, q3)          # the ensemble heads take no quantile samples
+    act = agent.forward(obs[:5])
+    assert act.dtype == torch.int64 and tuple(act.shape) == (5,) and int(act.min()) >= 0 and int(act.max()) < A
+    agent.eval()
+    greedy = agent.forward(obs[:5])
+    agent.train()
+    assert tuple(greedy.shape) == (5,)
+
+
+def test_ids_select_against_oracle_on_random_estimates(dev):
+    from oracle.learner_ref import ids_scores
+    from prism_amd import _native as N
+    rng = np.random.default_rng(11)
+    for n, T, A, heads in ((1, 200, 6, 10), (7, 32, 3, 2), (33, 200, 16, 10), (4, 1, 6, 1)):
+        dist = torch.from_numpy(rng.standard_normal((T, n, A)).astype(np.float32) * 2.0 + 1.0)
+        q = torch.from_numpy(rng.standard_normal((n, A, heads)).astype(np.float32))
+        n_pad = (n + 15) // 16 * 16
+        z = dist.permute(1, 0, 2).contiguous().to(dev)
+        qb = torch.zeros((heads, n_pad, A))
+        qb[:, :n] = q.permute(2, 0, 1)
+        qb = qb.to(dev)
+        scores = torch.empty((n, A), device=dev)
+        action = torch.empty(n, dtype=torch.int64, device=dev)
+        N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, heads, 0.1, 1e-10, 0.25, N.ptr(scores), None,
+                                         N.ptr(action), N.current_stream_handle()), "prism_ids_select")
+        torch.cuda.synchronize()
+        if T == 1 or heads == 1:
+            continue          # torch.var / torch.std of a single element are NaN in the reference too; only "does not fault"
+        r = ids_scores(dist, q, 0.1, 1e-10, 0.25)
+        np.testing.assert_allclose(scores.cpu().numpy(), r["scores"].numpy(), rtol=2e-4, atol=1e-7)
+        np.testing.assert_array_equal(action.cpu().numpy(), r["action"].numpy())
+
+
+def test_act_forward_rejects_bad_arguments(dev):
+    from prism_amd import _native as N
+    g, cfg, agent = updated_agent("iqn_small", dev)
+    obs = torch.zeros((4, 10, 10, int(g["C"])), device=dev)
+    agent.act_estimates(obs)
+    L, d = N.lib(), agent._desc
+    z = torch.empty((1024, 6), device=dev)
+    assert L.prism_act_forward(ctypes.byref(d), N.ptr(obs), 0, 8, None, 1, 0, N.ptr(z), None, None) == N.PRISM_ERR_INVALID
+    assert L.prism_act_forward(ctypes.byref(d), None, 4, 8, None, 1, 0, N.ptr(z), None, None) == N.PRISM_ERR_INVALID
+    assert L.prism_act_forward(ctypes.byref(d), N.ptr(obs), 4, 8, None, 1, 0, None, None, None) == N.PRISM_ERR_INVALID
+    assert L.prism_act_forward(ctypes.byref(d), N.ptr(obs), agent._B + 1, 8, None, 1, 0, N.ptr(z), None, None) == N.PRISM_ERR_INVALID

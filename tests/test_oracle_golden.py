@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from tests import helpers as H
-from oracle.learner_ref import LearnerOracle
+from oracle.learner_ref import LearnerOracle, act_forward, ids_scores
 
 LOSS_TOL = 1e-5       # BASELINE.json: loss parity to reference within 1e-5
 
@@ -48,3 +48,14 @@ def test_oracle_matches_reference_update(name):
                 np.testing.assert_allclose(v.numpy(), g[pre + "post/" + k], rtol=0, atol=2e-6)
         if cfg.use_target_network and step == 0:
             orc.sync_target()
+    # acting on the updated weights: CompositeModel.forward(for_action=True) and the IDS selector's intermediates
+    obs, taus, ref = H.case_act(g)
+    q, dist = act_forward(orc.state_dict(), orc.spec, obs, taus)
+    np.testing.assert_allclose(q.numpy(), ref["q"], rtol=0, atol=LOSS_TOL)
+    if dist is not None:
+        np.testing.assert_allclose(dist.numpy(), ref["dist"], rtol=0, atol=LOSS_TOL)
+    if cfg.use_ids:
+        r = ids_scores(dist, q, cfg.ids_lambda, cfg.ids_epsilon, cfg.ids_rho_lower_bound)
+        np.testing.assert_allclose(r["scores"].numpy(), ref["ids/IDS Scores"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(r["var_z"].numpy(), ref["ids/Return Distribution Variance"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_array_equal(r["action"].numpy(), ref["action"])

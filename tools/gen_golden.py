@@ -187,8 +187,31 @@ def gen_update_case(name, overrides, B, steps, store_full):
                 out[pre + "clipped_grad/" + k] = p.grad.numpy().copy()
         if cfg.use_target_network and step == 0:
             agent.sync_target_model()       # exercise hard sync between steps
+    # acting on the updated weights: Agent.forward's pieces (agent.py:31-41) for a handful of observations --
+    # CompositeModel.forward(for_action=True), then the training-time selector's scores / choice
+    n_act = 5
+    act_obs = (rng.random((n_act, 10, 10, C)) < 0.1).astype(np.float32)
+    torch.manual_seed(4242)
+    with torch.no_grad():
+        q, dist = agent.model(torch.from_numpy(act_obs), for_action=True)
+    out["act/obs_bits"] = np.packbits(act_obs.astype(np.uint8).reshape(-1))
+    out["act/n"] = n_act
+    out["act/q"] = q.numpy()
+    if cfg.use_iqn:
+        T_act = cfg.iqn_quantile_samples_per_action
+        torch.manual_seed(4242)
+        out["act/tau"] = torch.rand([T_act * n_act, 1]).float().numpy().reshape(-1)      # the draw iqn_model.py:66-68 made
+        out["act/dist"] = dist.numpy()
+    sel = agent.action_selector
+    with torch.no_grad():
+        probs = sel.generate_action_probs(dist, q, for_log=True) if cfg.use_ids else sel.generate_action_probs(dist, q)
+        out["act/action"] = sel.select_action(probs).numpy()
+    out["act/probs"] = probs.numpy()
+    if cfg.use_ids:
+        for k, v in sel.loggables.items():
+            out["act/ids/" + k] = v.numpy()
     np.savez_compressed(os.path.join(OUT, f"update_{name}.npz"), **out)
-    print(f"update_{name}: P={out['n_params']} total[-1]={out[pre + 'total']:.6f}")
+    print(f"update_{name}: P={out['n_params']} total[-1]={out[pre + 'total']:.6f} act={out['act/action'].tolist()}")
 
 
 def gen_nstep():
