@@ -218,6 +218,13 @@ typedef struct prism_learner_desc {
     const struct prism_replay_desc *fused_replay;   /* host pointer or NULL */
     const int64_t *fused_index;                     /* [B] sampled slots */
     float fused_alpha, fused_eps;
+    /* != 0 (fused hot path, single GPU only): prism_learner_fwd_bwd leaves the gradient partials unreduced and
+     * prism_step_back reduces them, clips and applies Adam in ONE launch (a grid barrier stands where the launch
+     * boundary was).  ld->grads is complete only after prism_step_back then, so nothing may sit between the two
+     * calls -- leave it 0 when an all-reduce does (hyper.grad_scale != 1 ignores it).  The library falls back to the
+     * separate launches by itself when the launch would not be resident at once.  Results are bit-identical. */
+    int32_t fuse_tail;
+    int32_t reserved0;
     /* outputs */
     float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */
     float *out_q_loss;        /* [B] or NULL  (Agent._static_q_loss)                          */
@@ -246,13 +253,14 @@ int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream);
 int prism_learner_clip_adam(const prism_learner_desc *ld, prism_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused hot path — one Learner iteration (prism/learner.py:95-125) in five launches (IQN; one or two
- * more with Q heads):
+ * Fused hot path — one Learner iteration (prism/learner.py:95-125) in four launches on one GPU (IQN; one or
+ * two more with Q heads), five when an all-reduce sits in the middle:
  *   prism_step_front                        PER sample + n-step gather + conv embed (+ LayerNorm helpers)
  *   prism_learner_fwd_bwd (embed_done = 1)  quantile forward tiles with the loss in their tail, column-sliced
- *                                           backward, post (gradient reduction + first half of the writeback)
+ *                                           backward [, post: gradient reduction + first half of the writeback]
  *   [RCCL all-reduce of ld->grads when data-parallel]
- *   prism_step_back                         clip + Adam, priority writeback with |td|, RNG counters
+ *   prism_step_back                         [fuse_tail: gradient reduction, then behind a grid barrier] clip + Adam,
+ *                                           priority writeback with |td|, RNG counters
  * Results are identical to per_sample -> replay_gather -> fwd_bwd -> clip_adam -> per_update.
  * ------------------------------------------------------------------------------------------ */
 /* TimestepBuffer.sample (timestep_buffer.py:35-51) fused with the embedding of both observations.

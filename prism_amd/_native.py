@@ -62,6 +62,7 @@ class LearnerDesc(ctypes.Structure):
                 ("tau_cur", c_vp), ("tau_next_online", c_vp), ("tau_next_target", c_vp), ("tau_out", c_vp),
                 ("seed", c_u64), ("offset", c_u64), ("rng_counters", c_vp),
                 ("fused_replay", c_vp), ("fused_index", c_vp), ("fused_alpha", c_f32), ("fused_eps", c_f32),
+                ("fuse_tail", c_i32), ("reserved0", c_i32),
                 ("out_dist_loss", c_vp), ("out_q_loss", c_vp), ("out_td", c_vp), ("out_scalars", c_vp),
                 ("dbg_z", c_vp), ("dbg_stamps", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
                 ("hyper", AdamHyper)]

@@ -197,6 +197,7 @@ class HipAgent:
             self.world = torch.distributed.get_world_size(process_group)
         self._B = None
         self.collective_in_graph = bool(getattr(config, "collective_in_graph", True))
+        self.fuse_tail = bool(getattr(config, "fuse_tail", True))
         self._capture_error = None
         self.model.train()
 
@@ -291,7 +292,7 @@ class HipAgent:
                 d.tau_next_target = next(it).data_ptr()
         d.seed = self.seed
         d.offset = self._draw_offset + self._fused_tau
-        d.rng_counters, d.embed_done, d.fused_replay = None, 0, None
+        d.rng_counters, d.embed_done, d.fused_replay, d.fuse_tail = None, 0, None, 0
         self._draw_offset += 3 * max(self.dims.n_tau, self.dims.n_tau_next) * B
         self._set_hyper()
         L = N.lib()
@@ -332,6 +333,8 @@ class HipAgent:
             d.fused_index, d.fused_alpha, d.fused_eps = buf._index.data_ptr(), smp._alpha, smp._eps
         else:
             d.fused_replay = None
+        # one GPU, whole step in one go: the gradient reduction rides in prism_step_back's launch (grid barrier)
+        d.fuse_tail = int(part == "all" and self.world == 1 and self.fuse_tail)
         if part in ("all", "front"):
             d.embed_done = 1
             N.check(L.prism_step_front(ctypes.byref(d), rp, buf._size, None, buf.seed, buf._draws,

@@ -29,7 +29,7 @@ void set_error(const char *fmt, ...);
 
 // ---- optional HIP-event instrumentation (profile.hip) ----
 enum KernelId { K_EMBED = 0, K_TILE_FWD, K_LOSS, K_BWD, K_POST, K_FRONT, K_CLIP_ADAM, K_PER_SAMPLE, K_GATHER,
-                K_PER_UPDATE, K_BACK, K_Q_FWD, K_Q_BWD };
+                K_PER_UPDATE, K_BACK, K_Q_FWD, K_Q_BWD, K_TAIL };
 extern thread_local int g_profile_on;
 void profile_begin(int kernel_id, hipStream_t stream);
 void profile_end(int kernel_id, hipStream_t stream);
@@ -54,6 +54,42 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // write back and invalidate the L2s) goes out as the kernel runs instead of in the flush at its end
 __device__ __forceinline__ void stream_store4(float4 *dst, const float4 &v) {
     __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(dst));
+}
+
+// Pull the kernel's whole argument segment into the scalar cache in ONE round trip.  The launch descriptors here are
+// 0.5 - 1.5 KB passed by value; the compiler fetches their fields where it first needs them, so a kernel that branches
+// on a field, then reads a pointer, then a size ... pays one scalar-cache miss (~0.4 us after a launch boundary)
+// PER step of that chain before its first vector load is even issued (measured: 2 us from entry to the first role
+// instruction of the post kernel).  One dword of every 64-byte line is requested back to back, into a register
+// nobody reads; the later field loads hit.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+    const char __attribute__((address_space(4))) *p =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = (BYTES - 4) / 64 + 1, GROUPS = (LINES + 7) / 8;
+    static_assert(GROUPS <= 4, "argument segment larger than 2 KB");
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#define PRISM_KA_GROUP(T, G)                                                                                          \
+    if constexpr (GROUPS > G) {                                                                                       \
+        constexpr int n = LINES - 8 * G >= 8 ? 8 : LINES - 8 * G;                                                     \
+        const char __attribute__((address_space(4))) *q = p + 512 * G;                                                \
+        if constexpr (n == 8)                                                                                         \
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\t"    \
+                         "s_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\t" \
+                         "s_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0" : "=&s"(T) : "s"(q));             \
+        else if constexpr (n >= 4)                                                                                    \
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\t"    \
+                         "s_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, %2" : "=&s"(T) : "s"(q), "n"(64 * (n - 1))); \
+        else                                                                                                          \
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, %2" : "=&s"(T) : "s"(q), "n"(64 * (n - 1)));  \
+    }
+    PRISM_KA_GROUP(t0, 0)
+    PRISM_KA_GROUP(t1, 1)
+    PRISM_KA_GROUP(t2, 2)
+    PRISM_KA_GROUP(t3, 3)
+#undef PRISM_KA_GROUP
+    // the registers stay allocated until every request has landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3));
 }
 
 // D = A(16x4) * B(4x16) + C, exact fp32 FMA chain.  Lane l supplies A[l&15][l>>4] and

@@ -60,6 +60,7 @@ struct FwRow {           // what a lane needs to know about tile row m
 
 template <int H, bool LN>
 __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
+    kernarg_prefetch<sizeof(IqnArgs)>();
     constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *cost = smem;                          // [16][CS] cos basis of the tile's rows

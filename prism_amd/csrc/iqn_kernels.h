@@ -491,6 +491,7 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
 // alone take 80 registers; two tile sets do not fit).
 template <int H, bool LN, bool DB>
 __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel(IqnArgs a) {
+    kernarg_prefetch<sizeof(IqnArgs)>();
     constexpr int NHT = H / 16, NU = H / 64, BWD_ACC = bwd_acc(H);
     constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);     // slab: phi_w | phi_b | [ln1_g | ln1_b] | w1
     typedef const f32x4 __attribute__((address_space(1))) *g4;

@@ -17,21 +17,6 @@
 
 namespace prism {
 
-// ---- global-norm clip + Adam over the flat buffers ---------------------------------------------
-struct AdamArgs {
-    float *p;
-    const float *g;
-    float *m, *v;
-    int64_t n;
-    int64_t *step;
-    const float *normpart;
-    int n_slots;
-    double lr, b1, b2, eps;
-    float max_norm, grad_scale;
-    float *out_scalars;
-    unsigned int *ticket;
-};
-
 // sum of squares of the (scaled) gradient, one partial per block — data-parallel path, where the
 // partials written by the backward kernels predate the all-reduce
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict__ g, int64_t n, float scale,
@@ -51,84 +36,11 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float *__restrict
     if (threadIdx.x == 0) normpart[blockIdx.x] = s_red[0];
 }
 
-// One 256-thread block of the clip + Adam update (block `blk` of `nblk`).
-__device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int nblk) {
-    __shared__ float s_red[256];
-    __shared__ float s_c[4];     // clip coef, -step_size, sqrt(bias_correction2)
-    const int tid = threadIdx.x;
-    // every block folds the same partials in the same order -> identical norm everywhere
-    float s = 0.f;
-#pragma unroll 4
-    for (int i = tid; i < a.n_slots; i += 256) s += a.normpart[i];
-    s_red[tid] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) s_red[tid] += s_red[tid + o];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const float total = sqrtf(s_red[0]);
-        float coef = a.max_norm / (total + 1e-6f);   // torch.nn.utils.clip_grad_norm_
-        coef = fminf(coef, 1.0f);
-        // torch.optim.Adam (_single_tensor_adam): bias corrections in float64 from the step count
-        const double t = (double)(a.step[0] + 1);
-        const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
-        s_c[0] = coef;
-        s_c[1] = (float)(-(a.lr / bc1));
-        s_c[2] = (float)sqrt(bc2);
-        if (blk == 0) {
-            a.out_scalars[3] = total;
-            a.out_scalars[5] = coef;
-        }
-    }
-    __syncthreads();
-    const float coef = s_c[0], neg_step = s_c[1], bc2s = s_c[2];
-    const float w1 = (float)(1.0 - a.b1), b2f = (float)a.b2, w2 = (float)(1.0 - a.b2), epsf = (float)a.eps;
-    const float gs = a.grad_scale;
-    auto upd = [&](float g_, float &p, float &m, float &v) {
-        const float g = (g_ * gs) * coef;
-        m = fmaf(w1, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * b2f + (w2 * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
-        const float denom = sqrtf(v) / bc2s + epsf;
-        p = p + (neg_step * m) / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
-    };
-    const int64_t nvec = a.n >> 2;
-    for (int64_t i = (int64_t)blk * 256 + tid; i < nvec; i += (int64_t)nblk * 256) {
-        const float4 g = reinterpret_cast<const float4 *>(a.g)[i];
-        float4 p = reinterpret_cast<float4 *>(a.p)[i];
-        float4 m = reinterpret_cast<float4 *>(a.m)[i];
-        float4 v = reinterpret_cast<float4 *>(a.v)[i];
-        upd(g.x, p.x, m.x, v.x);
-        upd(g.y, p.y, m.y, v.y);
-        upd(g.z, p.z, m.z, v.z);
-        upd(g.w, p.w, m.w, v.w);
-        stream_store4(reinterpret_cast<float4 *>(a.p) + i, p);
-        stream_store4(reinterpret_cast<float4 *>(a.m) + i, m);
-        stream_store4(reinterpret_cast<float4 *>(a.v) + i, v);
-    }
-    if (blk == 0 && tid < (int)(a.n & 3)) {
-        const int64_t i = (nvec << 2) + tid;
-        float p = a.p[i], m = a.m[i], v = a.v[i];
-        upd(a.g[i], p, m, v);
-        a.p[i] = p;
-        a.m[i] = m;
-        a.v[i] = v;
-    }
-    // the block that finishes last advances the step counter (every block has read it by then)
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int done = atomicAdd(a.ticket, 1u);
-        if (done == (unsigned)(nblk - 1)) {
-            a.step[0] = a.step[0] + 1;
-            *a.ticket = 0u;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) { clip_adam_block(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void clip_adam_kernel(AdamArgs a) { clip_adam_block<256>(a, blockIdx.x, gridDim.x); }
 
 // back: block 0 = priority writeback (+ RNG counters); blocks [1, gridDim) = clip + Adam.
 __global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay_desc rp, BackArgs k) {
+    kernarg_prefetch<sizeof(AdamArgs) + sizeof(prism_replay_desc) + sizeof(BackArgs)>();
     if (blockIdx.x == 0) {
         __shared__ __attribute__((aligned(16))) char s_pool[PER_UPDATE_LDS_BYTES];
         if (k.plan) per_update_finish(rp, k.plan, k.n, s_pool, k.sib, k.n, k.sib_state);
@@ -139,7 +51,7 @@ __global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay
         }
         return;
     }
-    clip_adam_block(a, blockIdx.x - 1, gridDim.x - 1);
+    clip_adam_block<256>(a, blockIdx.x - 1, gridDim.x - 1);
 }
 
 // ---- workspace carving -----------------------------------------------------------------------
@@ -210,7 +122,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     const size_t Hi = iqn_width(*d), Hq = head_width(*d);
     const int ln = d->use_layer_norm;
     IqnWs w;
-    w.ticket = (unsigned int *)c.f(4);     // first 16 bytes: the self-resetting tickets (zeroed once by the caller)
+    w.ticket = (unsigned int *)c.f(8);     // first 32 bytes: the self-resetting tickets (zeroed once by the caller)
     w.e_cur = c.f((size_t)B * E_DIM);
     w.e_next = c.f((size_t)B * E_DIM);
     w.uv = c.f(4 * Hi);
@@ -520,6 +432,55 @@ static hipError_t set_max_lds(const void *fn, size_t bytes) {
     return e;
 }
 
+// ---- the post launch: gradient slabs / small tensors / conv fold (+ priority writeback block); with `tail` also the
+// clip + Adam update behind a grid barrier (single GPU) ------------------------------------------------------------
+static int post_max_resident() {
+    static const int v = [] {
+        int dev = 0, cus = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true>, 1024, 0) != hipSuccess) return 0;
+        return cus * per;
+    }();
+    return v;
+}
+
+// The fused tail needs every workgroup of the launch resident at once (it has a grid barrier) and nothing between the
+// gradient and the optimizer step (no all-reduce: grad_scale 1).
+static bool tail_fused(const prism_learner_desc *ld) {
+    if (!ld->fuse_tail || ld->hyper.grad_scale != 1.0f) return false;
+    static const bool off = [] { const char *e = getenv("PRISM_NO_FUSED_TAIL"); return e && atoi(e) != 0; }();
+    if (off) return false;
+    return post_block_count(ld) + 1 <= post_max_resident();
+}
+
+static int launch_post(const prism_learner_desc *ld, const IqnArgs &a, const TailArgs *tail, hipStream_t stream) {
+    ProfileScope ps_(tail ? K_TAIL : K_POST, stream);
+    int nb = post_block_count(ld);
+    PostWriteback wb;
+    memset(&wb, 0, sizeof(wb));
+    if (ld->fused_replay && ld->fused_replay->tree && ld->fused_index) {
+        // TD errors are final: the priority writeback rides along as one more block of this launch
+        wb.enabled = 1;
+        wb.rp = *ld->fused_replay;
+        wb.index = ld->fused_index;
+        wb.sib = reinterpret_cast<const float2 *>(a.ws.sib);
+        wb.sib_state = a.ws.ticket + 3;
+        wb.plan = (!tail && split_writeback(ld)) ? reinterpret_cast<int4 *>(a.ws.wb_plan) : nullptr;
+        wb.alpha = ld->fused_alpha;
+        wb.eps = ld->fused_eps;
+        wb.block = nb;
+        nb += 1;
+    }
+    TailArgs none;
+    memset(&none, 0, sizeof(none));
+    if (tail) hipLaunchKernelGGL((iqn_post_kernel<true, true>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
+    else if (wb.plan) hipLaunchKernelGGL((iqn_post_kernel<false, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
+    else hipLaunchKernelGGL((iqn_post_kernel<true, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
+    PRISM_CHECK_LAUNCH();
+    return PRISM_OK;
+}
+
 extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_t stream_) {
     int rc = check_learner(ld);
     if (rc) return rc;
@@ -625,27 +586,9 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         }
         PRISM_CHECK_LAUNCH();
     }
-    {
-        ProfileScope ps_(K_POST, stream);
-        int nb = post_block_count(ld);
-        PostWriteback wb;
-        memset(&wb, 0, sizeof(wb));
-        if (ld->fused_replay && ld->fused_replay->tree && ld->fused_index) {
-            // TD errors are final: the priority writeback rides along as one more block of this launch
-            wb.enabled = 1;
-            wb.rp = *ld->fused_replay;
-            wb.index = ld->fused_index;
-            wb.sib = reinterpret_cast<const float2 *>(a.ws.sib);
-            wb.sib_state = a.ws.ticket + 3;
-            wb.plan = split_writeback(ld) ? reinterpret_cast<int4 *>(a.ws.wb_plan) : nullptr;
-            wb.alpha = ld->fused_alpha;
-            wb.eps = ld->fused_eps;
-            wb.block = nb;
-            nb += 1;
-        }
-        if (wb.plan) hipLaunchKernelGGL(iqn_post_kernel<false>, dim3(nb), dim3(1024), 0, stream, a, wb);
-        else hipLaunchKernelGGL(iqn_post_kernel<true>, dim3(nb), dim3(1024), 0, stream, a, wb);
-        PRISM_CHECK_LAUNCH();
+    if (!tail_fused(ld)) {
+        rc = launch_post(ld, a, nullptr, stream);
+        if (rc) return rc;
     }
     if (ld->dbg_z) {
         const size_t R = (size_t)B * ld->dims.n_tau, Rn = (size_t)B * ld->dims.n_tau_next, A = ld->dims.n_actions;
@@ -866,6 +809,26 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
     const int maxT = ld->dims.n_tau > ld->dims.n_tau_next ? ld->dims.n_tau : ld->dims.n_tau_next;
     k.inc_per = (uint64_t)ld->batch;
     k.inc_tau = (uint64_t)3 * maxT * ld->batch;
+    if (tail_fused(ld)) {
+        // single GPU: gradient reduction + clip + Adam + writeback in one launch
+        IqnArgs ia;
+        fill_iqn_args(ld, ia);
+        TailArgs t;
+        t.adam = a;
+        t.barrier = ws.ticket + 4;
+        t.rng = k.rng;
+        t.inc_per = k.inc_per;
+        t.inc_tau = k.inc_tau;
+        rc = launch_post(ld, ia, &t, stream);
+        if (rc) return rc;
+        if (k.use_per) {          // prioritised replay that is not riding in the learner's launches: its own update
+            const int threads = ld->batch >= 1024 ? 1024 : ((ld->batch + 127) / 128) * 128;
+            hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(threads), 0, stream, *rp, index, ld->out_td, ld->batch, alpha, eps,
+                               1);
+            PRISM_CHECK_LAUNCH();
+        }
+        return PRISM_OK;
+    }
     {
         ProfileScope ps_(K_BACK, stream);
         hipLaunchKernelGGL(step_back_kernel, dim3(1 + adam_blocks(a.n)), dim3(256), 0, stream, a, *rp, k);

@@ -73,7 +73,7 @@ extern "C" const char *prism_profile_kernel_name(int id) {
         "iqn_embed_kernel", "fwd_tile_kernel",     "iqn_loss_kernel",      "iqn_bwd_kernel",
         "iqn_post_kernel",  "step_front_kernel",   "clip_adam_kernel",     "per_sample_kernel",
         "replay_gather_kernel", "per_update_kernel", "step_back_kernel",   "qh_loss_kernel",
-        "qh_bwd_kernel",     "",                    "",                     ""};
+        "qh_bwd_kernel",     "step_tail_kernel",    "",                     ""};
     if (id < 0 || id >= PRISM_N_KERNEL_IDS) return "";
     return names[id];
 }

@@ -192,8 +192,8 @@ __device__ __forceinline__ uint32_t count_less(const uint64_t *keys, int j0, int
 
 // rank of (leaf, tid) among the cnt keys; K = uint32_t while leaf << UPD_POS_BITS fits, else uint64_t
 template <typename K>
-__device__ __forceinline__ int block_rank(int32_t my_idx, int cnt, K *s_key, uint16_t *s_part) {
-    const int tid = threadIdx.x, bd = blockDim.x;
+__device__ __forceinline__ int block_rank(int32_t my_idx, int cnt, K *s_key, uint16_t *s_part, int bd) {
+    const int tid = threadIdx.x;
     const int cnt4 = (cnt + 3) & ~3;
     if (tid < cnt4) s_key[tid] = tid < cnt ? (((K)(uint32_t)my_idx << UPD_POS_BITS) | (K)tid) : ~(K)0;
     lds_only_barrier();
@@ -245,7 +245,7 @@ __device__ __forceinline__ void tree_sib_prefetch(const prism_replay_desc &rp, i
 }
 
 __device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t leaf, float my_val, int cnt, int levels,
-                                                       char *lds) {
+                                                       char *lds, int bd) {
     const int tid = threadIdx.x;
     const bool active = tid < cnt;
     int32_t *s_sorted = reinterpret_cast<int32_t *>(lds);               // [UPD_MAX] leaves in rank order
@@ -253,8 +253,8 @@ __device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t l
     uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials
     char *s_keys = lds + UPD_MAX * 12;                                  // ranking keys alias the records
     TreePrep p;
-    p.rank = levels + UPD_POS_BITS <= 32 ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_keys), s_part)
-                                         : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_keys), s_part);
+    p.rank = levels + UPD_POS_BITS <= 32 ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_keys), s_part, bd)
+                                         : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_keys), s_part, bd);
     TREE_STAMP(25);
     if (active) {
         s_sorted[p.rank] = leaf;
@@ -329,7 +329,8 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
 
 // all three in one workgroup: among equal leaves the highest t wins
 __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
-                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0) {
+                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0, int bd = 0) {
+    if (!bd) bd = (int)blockDim.x;
     const bool active = (int)threadIdx.x < cnt;
     const int64_t cap = rp.tree_capacity;
     const int levels = 63 - __clzll((unsigned long long)cap);
@@ -338,7 +339,7 @@ __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, in
     SibRegs sr;
     tree_sib_prefetch(rp, leaf, active, levels, sib, sib_stride, sr);
     TREE_STAMP(23);
-    const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, levels, lds);
+    const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, levels, lds, bd);
     tree_write_levels(rp, leaf, p, cnt, levels, lds, sr);
 }
 
@@ -353,10 +354,14 @@ template <bool PREPARE_ONLY = false>
 __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
                                  char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0,
-                                 int4 *__restrict__ plan_out = nullptr) {
+                                 int4 *__restrict__ plan_out = nullptr, int live_threads = 0) {
     float *s_red = reinterpret_cast<float *>(lds + TREE_WRITE_LDS_BYTES);
     const int tid = threadIdx.x;
-    const int pass = min(UPD_MAX, (int)blockDim.x);
+    // `live_threads` (a multiple of 64, >= n rounded up): the caller has already retired the waves above it -- a
+    // workgroup that hosts this role with more waves than the batch needs pays for every one of them at each of the
+    // ~25 workgroup barriers below (hardware barriers only count waves that have not ended)
+    const int bd = live_threads ? live_threads : (int)blockDim.x;
+    const int pass = min(UPD_MAX, bd);
     TREE_STAMP(0);
     // first pass's operands and the running max get in flight together
     const float old_max = tid == 0 ? rp.per_state[0] : 0.f;
@@ -369,7 +374,7 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
     }
     // running max of the raw priorities (torchrl tracks it before the +eps, **alpha)
     float m = tid < min(pass, n) ? p0 : -FLT_MAX;
-    for (int i = pass + tid; i < n; i += blockDim.x) {
+    for (int i = pass + tid; i < n; i += bd) {
         float p = priority[i];
         if (take_abs) p = fabsf(p);
         m = fmaxf(m, p);
@@ -394,14 +399,14 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
             const int64_t cap = rp.tree_capacity;
             const int levels = 63 - __clzll((unsigned long long)cap);
             const int32_t leaf = tid < cnt ? (int32_t)((int64_t)me | cap) : (int32_t)cap;
-            const TreePrep p = tree_write_prepare(me, leaf, val, cnt, levels, lds);
+            const TreePrep p = tree_write_prepare(me, leaf, val, cnt, levels, lds, bd);
             if (tid < cnt) plan_out[tid] = make_int4(__float_as_int(p.val), p.lo | (p.hi << 16), leaf, p.rank);
         } else {
-            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride);   // a record is only
+            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride, bd);   // a record is only
         }                                                                                      // valid for one pass
         if (base == 0 && tid == 0) {
             float mm = old_max;                                 // (s_red was published before the first barrier)
-            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, s_red[w]);
+            for (int w = 0; w < (bd >> 6); ++w) mm = fmaxf(mm, s_red[w]);
             rp.per_state[0] = mm;
         }
     }

@@ -87,6 +87,7 @@ struct FrontArgs {
 // observations;  blocks [B, B + H/4): u = W1 g1, v = W1 beta1;  then PACK_BLOCKS (x2 with a target
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
 __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
+    kernarg_prefetch<sizeof(IqnArgs) + sizeof(prism_replay_desc) + sizeof(FrontArgs)>();
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ __attribute__((aligned(16))) float s_scratch[256];
     __shared__ float s_obs[2][1000];
@@ -279,6 +280,248 @@ __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     return t;   // valid in thread 0
 }
 
+// ---- global-norm clip + Adam over the flat buffers ---------------------------------------------
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m, *v;
+    int64_t n;
+    int64_t *step;
+    const float *normpart;
+    int n_slots;
+    double lr, b1, b2, eps;
+    float max_norm, grad_scale;
+    float *out_scalars;
+    unsigned int *ticket;
+};
+
+// One NT-thread block of the clip + Adam update (block `blk` of `nblk`).  The operands of the block's first
+// float4 per thread are requested BEFORE the norm is folded: the fold's own loads and two barriers then ride on the
+// same memory round trip.  The fold itself is always the 256-lane form (strided partial sums, LDS tree), whatever NT:
+// every launch shape arrives at the same bits for the norm.
+template <int NT>
+__device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int nblk) {
+    __shared__ float s_red[256];
+    __shared__ float s_c[4];     // clip coef, -step_size, sqrt(bias_correction2)
+    const int tid = threadIdx.x;
+    const int64_t nvec = a.n >> 2;
+    const int64_t i0 = (int64_t)blk * NT + tid;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), p0 = g0, m0 = g0, v0 = g0;
+    if (i0 < nvec) {
+        g0 = reinterpret_cast<const float4 *>(a.g)[i0];
+        p0 = reinterpret_cast<const float4 *>(a.p)[i0];
+        m0 = reinterpret_cast<const float4 *>(a.m)[i0];
+        v0 = reinterpret_cast<const float4 *>(a.v)[i0];
+    }
+    // every block folds the same partials in the same order -> identical norm everywhere
+    if (tid < 256) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int i = tid; i < a.n_slots; i += 256) s += a.normpart[i];
+        s_red[tid] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float total = sqrtf(s_red[0]);
+        float coef = a.max_norm / (total + 1e-6f);   // torch.nn.utils.clip_grad_norm_
+        coef = fminf(coef, 1.0f);
+        // torch.optim.Adam (_single_tensor_adam): bias corrections in float64 from the step count
+        const double t = (double)(a.step[0] + 1);
+        const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
+        s_c[0] = coef;
+        s_c[1] = (float)(-(a.lr / bc1));
+        s_c[2] = (float)sqrt(bc2);
+        if (blk == 0) {
+            a.out_scalars[3] = total;
+            a.out_scalars[5] = coef;
+        }
+    }
+    __syncthreads();
+    const float coef = s_c[0], neg_step = s_c[1], bc2s = s_c[2];
+    const float w1 = (float)(1.0 - a.b1), b2f = (float)a.b2, w2 = (float)(1.0 - a.b2), epsf = (float)a.eps;
+    const float gs = a.grad_scale;
+    auto upd = [&](float g_, float &p, float &m, float &v) {
+        const float g = (g_ * gs) * coef;
+        m = fmaf(w1, g - m, m);                 // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * b2f + (w2 * g) * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+        const float denom = sqrtf(v) / bc2s + epsf;
+        p = p + (neg_step * m) / denom;         // param.addcdiv_(exp_avg, denom, value=-step_size)
+    };
+    auto upd4 = [&](int64_t i, const float4 &g, float4 p, float4 m, float4 v) {
+        upd(g.x, p.x, m.x, v.x);
+        upd(g.y, p.y, m.y, v.y);
+        upd(g.z, p.z, m.z, v.z);
+        upd(g.w, p.w, m.w, v.w);
+        stream_store4(reinterpret_cast<float4 *>(a.p) + i, p);
+        stream_store4(reinterpret_cast<float4 *>(a.m) + i, m);
+        stream_store4(reinterpret_cast<float4 *>(a.v) + i, v);
+    };
+    if (i0 < nvec) upd4(i0, g0, p0, m0, v0);
+    for (int64_t i = i0 + (int64_t)nblk * NT; i < nvec; i += (int64_t)nblk * NT)
+        upd4(i, reinterpret_cast<const float4 *>(a.g)[i], reinterpret_cast<float4 *>(a.p)[i],
+             reinterpret_cast<float4 *>(a.m)[i], reinterpret_cast<float4 *>(a.v)[i]);
+    if (blk == 0 && tid < (int)(a.n & 3)) {
+        const int64_t i = (nvec << 2) + tid;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        upd(a.g[i], p, m, v);
+        a.p[i] = p;
+        a.m[i] = m;
+        a.v[i] = v;
+    }
+    // the block that finishes last advances the step counter (every block has read it by then)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = atomicAdd(a.ticket, 1u);
+        if (done == (unsigned)(nblk - 1)) {
+            a.step[0] = a.step[0] + 1;
+            *a.ticket = 0u;
+        }
+    }
+}
+
+// Grid-wide barrier for a launch whose workgroups are ALL resident at once (the host checks the occupancy before it
+// picks a kernel that calls this).  Publish: every wave drains its own stores, the workgroup meets, one lane writes the
+// L2 back (release), counts the workgroup in and -- unless it was the last to arrive -- polls the counter past the L2
+// (agent scope) until all `n` arrived, then invalidates (acquire) before anyone reads what the others wrote.
+// The counter is NOT reset here (that would put one more memory round trip on every workgroup's path): the caller
+// zeroes it once every workgroup is known to be past the barrier (the tail does it with its last-finisher ticket).
+__device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(ctr, 1u) != n - 1)
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// the clip + Adam half of the step when it rides in the post launch (single GPU: nothing sits between the two)
+struct TailArgs {
+    AdamArgs adam;
+    unsigned int *barrier;     // [2] arrivals, departures
+    uint64_t *rng;             // device RNG counters {PER draws, tau draws} advanced once per step (or NULL)
+    uint64_t inc_per, inc_tau;
+};
+
+// Which float4 of the flat vectors a thread of the fused tail updates.  A slab block keeps the gradient it has just
+// summed (`own`: no reload); the other role blocks share what lies outside the slab range [s0, s0 + cnt): leftover
+// number k is float4 k below s0 and k + cnt above.
+struct TailShare {
+    int64_t j;        // first float4 of this thread
+    bool have, own;
+    float4 g;         // the owned gradient
+    int64_t k, kstride, nleft, s0, cnt;     // leftover walk (kstride 0: none)
+    bool scalar_tail; // this block also updates the n & 3 trailing elements
+};
+
+// Clip + Adam behind the grid barrier (1024 threads).  Everything that does not depend on the other workgroups is
+// requested or computed BEFORE the barrier and lands while the workgroup waits in it: the thread's parameter / moment
+// vectors and the float64 bias corrections (another wave than the one that polls).  Behind it: the norm partials (and
+// the gradient where it is not owned), the 256-lane fold every launch shape uses, the update.  Bit-identical to
+// clip_adam_block.
+__device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned int *barrier, int n_role, const TailShare &sh,
+                                               unsigned long long *st) {
+    auto stamp = [&](int k) {
+        if (st && threadIdx.x == 0) {
+            st[(size_t)blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
+            st[(size_t)blockIdx.x * 64 + 32 + k] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    __shared__ float s_red[256];
+    __shared__ float s_c[4];
+    const int tid = threadIdx.x;
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0;
+    if (sh.have) {
+        p0 = reinterpret_cast<const float4 *>(a.p)[sh.j];
+        m0 = reinterpret_cast<const float4 *>(a.m)[sh.j];
+        v0 = reinterpret_cast<const float4 *>(a.v)[sh.j];
+    }
+    if (tid == 64) {
+        const double t = (double)(a.step[0] + 1);
+        const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
+        s_c[1] = (float)(-(a.lr / bc1));
+        s_c[2] = (float)sqrt(bc2);
+    }
+    grid_barrier(barrier, (unsigned)n_role);
+    stamp(25);
+    float4 g0 = sh.g;
+    if (sh.have && !sh.own) g0 = reinterpret_cast<const float4 *>(a.g)[sh.j];
+    if (tid < 256) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int i = tid; i < a.n_slots; i += 256) s += a.normpart[i];
+        s_red[tid] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_red[tid] += s_red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float total = sqrtf(s_red[0]);
+        float coef = a.max_norm / (total + 1e-6f);
+        coef = fminf(coef, 1.0f);
+        s_c[0] = coef;
+        if (blockIdx.x == 0) {
+            a.out_scalars[3] = total;
+            a.out_scalars[5] = coef;
+        }
+    }
+    __syncthreads();
+    stamp(15);
+    const float coef = s_c[0], neg_step = s_c[1], bc2s = s_c[2];
+    const float w1 = (float)(1.0 - a.b1), b2f = (float)a.b2, w2 = (float)(1.0 - a.b2), epsf = (float)a.eps;
+    const float gs = a.grad_scale;
+    auto upd = [&](float g_, float &p, float &m, float &v) {
+        const float g = (g_ * gs) * coef;
+        m = fmaf(w1, g - m, m);
+        v = v * b2f + (w2 * g) * g;
+        const float denom = sqrtf(v) / bc2s + epsf;
+        p = p + (neg_step * m) / denom;
+    };
+    auto upd4 = [&](int64_t i, const float4 &g, float4 p, float4 m, float4 v) {
+        upd(g.x, p.x, m.x, v.x);
+        upd(g.y, p.y, m.y, v.y);
+        upd(g.z, p.z, m.z, v.z);
+        upd(g.w, p.w, m.w, v.w);
+        stream_store4(reinterpret_cast<float4 *>(a.p) + i, p);
+        stream_store4(reinterpret_cast<float4 *>(a.m) + i, m);
+        stream_store4(reinterpret_cast<float4 *>(a.v) + i, v);
+    };
+    if (sh.have) upd4(sh.j, g0, p0, m0, v0);
+    if (sh.kstride)
+        for (int64_t k = sh.k + sh.kstride; k < sh.nleft; k += sh.kstride) {
+            const int64_t i = k < sh.s0 ? k : k + sh.cnt;
+            upd4(i, reinterpret_cast<const float4 *>(a.g)[i], reinterpret_cast<float4 *>(a.p)[i],
+                 reinterpret_cast<float4 *>(a.m)[i], reinterpret_cast<float4 *>(a.v)[i]);
+        }
+    if (sh.scalar_tail && tid < (int)(a.n & 3)) {
+        const int64_t i = ((a.n >> 2) << 2) + tid;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        upd(a.g[i], p, m, v);
+        a.p[i] = p;
+        a.m[i] = m;
+        a.v[i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int done = atomicAdd(a.ticket, 1u);
+        if (done == (unsigned)(n_role - 1)) {     // everybody is past the barrier: step counter, tickets ready for the next launch
+            a.step[0] = a.step[0] + 1;
+            *a.ticket = 0u;
+            *barrier = 0u;
+        }
+    }
+}
+
 struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as the last block of the post launch
     prism_replay_desc rp;
     const int64_t *index;
@@ -292,8 +535,13 @@ struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as 
 
 // WB_FULL: the writeback block runs the whole update (batches above 256); otherwise it only prepares
 // it (two instantiations: the full writer's register arrays would otherwise tax every role with spills)
-template <bool WB_FULL>
-__global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb) {
+// TAIL: the launch also clips and applies Adam (single GPU): a grid barrier after the partial norms, then every role
+// block updates its share of the flat parameter vector; the writeback block (always the full writer then) advances the
+// device RNG counters and does not take part in the barrier.
+template <bool WB_FULL, bool TAIL>
+__global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb, TailArgs tl) {
+    static_assert(WB_FULL || !TAIL, "the fused tail has nobody to finish a prepared writeback");
+    kernarg_prefetch<sizeof(IqnArgs) + sizeof(PostWriteback) + sizeof(TailArgs)>();
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
     constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
                                                                                        : (int)(CONV_LDS_FLOATS * sizeof(float));
@@ -306,9 +554,16 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             per_update_block<true>(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, nullptr, 0, wb.plan);
         } else {
             const unsigned int rec = wb.sib_state ? *wb.sib_state : 0u;
+            // waves the batch does not need leave now (one pass: B <= 512)
+            const int live = a.B <= UPD_MAX ? min(1024, 2 * ((a.B + 63) & ~63)) : 0;     // (x2: the ranking splits its count two ways)
+            if (live && (int)threadIdx.x >= live) return;
             per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, rec == 1u ? wb.sib : nullptr,
-                             a.B);
+                             a.B, nullptr, live);
             if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;  // (every thread read it before its first barrier)
+        }
+        if (TAIL && tl.rng && threadIdx.x == 0) {
+            tl.rng[0] += tl.inc_per;
+            tl.rng[1] += tl.inc_tau;
         }
         PRISM_STAMP(14);
         return;
@@ -320,6 +575,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     const int n_conv = dqn1 ? dqn1_conv_blocks(C) : (a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB);
     int blk = blockIdx.x;
     float sq = 0.f;
+    float4 g_own = make_float4(0.f, 0.f, 0.f, 0.f);     // (fused tail) the slab sum of this thread, kept for its Adam update
     if (dqn1 && blk < n_conv) {
         // fold the per-sample rows of the loss kernel: 64 outputs x 16 batch parts per workgroup
         float *s_part = reinterpret_cast<float *>(s_pool);           // [16][CONV_FOLD_W]
@@ -407,6 +663,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             const int n_slab = post_slab_blocks(a.slab), n_small = post_small_blocks(a.Hi);
             if (blk < n_slab) {
                 const int i = blk * 1024 + tid;
+                PRISM_STAMP(8);
                 if (i < a.slab / 4) {
                     float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
                     float4 v[7];
@@ -418,8 +675,11 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                         if (c < a.n_chunks) {
                             s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
                         }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    PRISM_STAMP(7);
                     stream_store4(reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i), s);
                     sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+                    g_own = s;
                 }
                 done = true;
             } else if (blk < n_slab + n_small) {
@@ -485,6 +745,36 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     const float t = block_sum_1024(sq, s_red);
     if (tid == 0) a.ws.normpart[blockIdx.x] = t;
     PRISM_STAMP(14);
+    if constexpr (TAIL) {
+        const int n_role = wb.enabled ? (int)gridDim.x - 1 : (int)gridDim.x;
+        const int n_slab = a.use_iqn ? post_slab_blocks(a.slab) : 0;
+        const int sb = (int)blockIdx.x - n_conv;
+        TailShare sh;
+        sh.nleft = (tl.adam.n >> 2) - (a.use_iqn ? a.slab >> 2 : 0);
+        sh.s0 = a.use_iqn ? a.off.phi_w >> 2 : 0;
+        sh.cnt = a.use_iqn ? a.slab >> 2 : 0;
+        sh.g = g_own;
+        if (a.use_iqn && sb >= 0 && sb < n_slab) {
+            sh.own = sh.have = (int64_t)sb * 1024 + tid < sh.cnt;
+            sh.j = sh.s0 + (int64_t)sb * 1024 + tid;
+            sh.k = sh.kstride = 0;
+            sh.scalar_tail = false;
+        } else {
+            const int rank = (int)blockIdx.x < n_conv ? (int)blockIdx.x : (int)blockIdx.x - n_slab;
+            sh.own = false;
+            sh.k = (int64_t)rank * 1024 + tid;
+            sh.kstride = (int64_t)(n_role - n_slab) * 1024;
+            sh.have = sh.k < sh.nleft;
+            sh.j = sh.k < sh.s0 ? sh.k : sh.k + sh.cnt;
+            sh.scalar_tail = rank == 0;
+        }
+        tail_clip_adam(tl.adam, tl.barrier, n_role, sh, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
+        if (!wb.enabled && tl.rng && blockIdx.x == 0 && tid == 0) {
+            tl.rng[0] += tl.inc_per;
+            tl.rng[1] += tl.inc_tau;
+        }
+        PRISM_STAMP(9);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
     assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4
     # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40)
-    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 7 * 8 + 8 + 40
+    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 7 * 8 + 8 + 40
 
 
 def test_argument_checks_without_device(lib):

@@ -1,4 +1,4 @@
-"""GPU: the fused six-launch step and its hipGraph replay produce exactly what the unfused
+"""GPU: the fused four-/five-launch step and its hipGraph replay produce exactly what the unfused
 sample() -> update() -> update_priority() sequence produces (same Philox streams)."""
 import contextlib
 import io
@@ -10,12 +10,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _mk(dev, fused, graph, B=32, cap=4096, base=2, **over):
+def _mk(dev, fused, graph, B=32, cap=4096, base=2, fuse_tail=True, **over):
     from prism_amd.config import baseline_config
     from prism_amd.learner import Learner
     from prism_amd.synthetic import fill_replay
     cfg = baseline_config(base, device=dev, batch_size=B, experience_replay_capacity=cap, **over)
-    cfg.fused_step, cfg.hip_graph = fused, graph
+    cfg.fused_step, cfg.hip_graph, cfg.fuse_tail = fused, graph, fuse_tail
     ln = Learner()
     with contextlib.redirect_stdout(io.StringIO()):
         ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
@@ -31,9 +31,12 @@ def test_fused_and_graph_equal_unfused(over):
         pytest.skip("needs a GPU")
     dev = "cuda:0"
     ref, fus, gra = _mk(dev, False, False, **over), _mk(dev, True, False, **over), _mk(dev, True, True, **over)
+    # (fus / gra: four launches, the gradient reduction and clip + Adam behind a grid barrier in one; spl: the five-launch
+    # form a data-parallel step uses, without the all-reduce)
+    spl = _mk(dev, True, True, fuse_tail=False, **over)
     for step in range(6):
         outs = []
-        for ln in (ref, fus, gra):
+        for ln in (ref, fus, gra, spl):
             td = ln.step(timesteps_this_iteration=1).clone()
             torch.cuda.synchronize()
             buf, ag = ln.experience_buffer, ln.agent

@@ -88,7 +88,17 @@ order = np.argsort(-d_)[:10]
 print("   longest post blocks (index: ticks):", ", ".join(f"{int(idx[i])}: {int(d_[i])}" for i in order))
 print("   post block duration by index decile:", [int(np.median(d_[(idx >= lo_) & (idx < hi_)])) if ((idx >= lo_) & (idx < hi_)).any() else 0
       for lo_, hi_ in zip(np.linspace(0, idx.max() + 1, 11)[:-1], np.linspace(0, idx.max() + 1, 11)[1:])])
-if os.environ.get("STAMP_DEBUG"):
-    v = np.sort(s[:nfw, 0].astype(np.int64))
-    print("fwd start stamps sorted (first 6, last 6):", v[:6], v[-6:])
-    print("fwd rows with zero start:", np.nonzero(s[:nfw, 0] == 0)[0][:10], " nfw", nfw, " nonzero rows beyond:", np.nonzero(s[nfw:, 0])[0][:5])
+sl = s[n_conv:n_conv + 49].astype(np.float64)
+if sl[:, 7].any():
+    print("   slab phases (kernel entry -> role code reached | 8 chunk loads arrived | store + norm partial written):",
+          [int(np.median(x)) for x in (sl[:, 8] - sl[:, 13], sl[:, 7] - sl[:, 8], sl[:, 14] - sl[:, 7])])
+# fused tail (slots 25 = past the grid barrier, 9 = Adam done), role blocks only
+tb = pb & (s[:, 25] != 0)
+if tb.any():
+    w_, a_ = (s[tb, 25] - s[tb, 14]).astype(np.float64), (s[tb, 9] - s[tb, 25]).astype(np.float64)
+    c_ = (s[tb, 15] - s[tb, 25]).astype(np.float64)
+    print(f"   tail: wait at the grid barrier med {np.median(w_):.0f} min {w_.min():.0f} max {w_.max():.0f};  clip + Adam med {np.median(a_):.0f} max {a_.max():.0f}"
+          f" (of which norm partials + fold: {np.median(c_):.0f})")
+    rs, re_ = s[pb, 32 + 13].astype(np.float64), np.where(s[pb, 32 + 9] != 0, s[pb, 32 + 9], s[pb, 32 + 14]).astype(np.float64)
+    print(f"   tail real time: first start -> last role block past the barrier {(s[tb, 32 + 25].max() - rs.min()) / 100:.2f} us, -> last end {(re_.max() - rs.min()) / 100:.2f} us;"
+          f"  writeback block {(s[idx.max(), 32 + 14] - s[idx.max(), 32 + 13]) / 100:.2f} us")
