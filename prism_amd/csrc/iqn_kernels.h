@@ -73,7 +73,8 @@ struct IqnWs {           // workspace pointers (device)
     float *normpart;     // [NORM_SLOTS]
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
     float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
-    unsigned int *ticket;   // [4] {adam, conv, -, sibling-record state}, zero-initialised by the caller, self-resetting
+    unsigned int *ticket;   // [8] {adam, conv, -, sibling-record state | grid barrier of the fused tail: two 64-bit
+                            // counters, arrivals and launches}, zero-initialised by the caller; the first four reset themselves
 };
 
 constexpr int NORM_SLOTS = 2560;
@@ -240,6 +241,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // shader-clock stamps (s_memtime: per-XCD counters, only differences inside one workgroup mean anything) plus,
 // in slots 60.. the chip-wide 100 MHz real-time counter of the same moments (for spans across workgroups)
+#define PRISM_LOOP_STAMP(k)                                                                \
+    do {                                                                                   \
+        if ((a.dbg & 16) && threadIdx.x == 0 && blockIdx.x >= 256)                         \
+            a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
 #define PRISM_STAMP(k)                                                                     \
     do {                                                                                   \
         if ((a.dbg & 8) && threadIdx.x == 0) {                                             \
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
         // ---- phi columns and dX columns: three independent MFMA chains interleaved -------------------
         f32x4 aphi = {bphi, bphi, bphi, bphi}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
+        if (ti < 4) PRISM_LOOP_STAMP(16 + 4 * ti);
 #pragma unroll
         for (int q = 0; q < NHT / 2; ++q) {
             f32x4 wa, wb, wp = {0.f, 0.f, 0.f, 0.f};
@@ -663,6 +670,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             if (q & 1) __builtin_amdgcn_sched_barrier(0);      // (bounds how many weight registers are in flight)
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (ti < 4) PRISM_LOOP_STAMP(17 + 4 * ti);
         if (!DB && more) load_rows_a(S, ti + 1);  // the row-on-lane registers are free: refill them for the next tile
         __builtin_amdgcn_sched_barrier(0);
         // ---- elementwise backward of row group r (column n), then the weight-gradient MFMAs of that group:
@@ -697,6 +705,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
                 for (int c = 0; c < 4; ++c) accW1[4 * u + c] = mfma16(S.dB[r][u][c], xr, accW1[4 * u + c]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (ti < 4) PRISM_LOOP_STAMP(18 + 4 * ti);
         const bool ev_pos = ev > 0.f;
         if (!DB && more) {
             load_rows_b(S, ti + 1);
@@ -722,6 +731,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             }
         }
         if (n_mine) s_dcv[ti * 64 + lane] = dcv;
+        if (ti < 4) PRISM_LOOP_STAMP(19 + 4 * ti);
     };
     if (DB) {
         for (int ti = 0; ti < tiles_per_wave; ti += 2) {
@@ -946,10 +956,10 @@ struct SmallIo {
     const float *extra;                     // optional [B]: slice 0 leaves sum_b extra[b] in *extra_sum (thread 0)
     int w_stride;                           // row stride of w2 / gw2 (units per action row)
 };
-// load(b, h, want_d) -> {v, p, d}
-template <typename Load>
-__device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, float &sq, float *pool, const SmallIo &io,
-                                                 Load load, float *extra_sum) {
+// load(b, h, want_d) -> {v, p, d}.  AMAX: action slots carried per thread (7: up to seven actions, one LDS pass).
+template <int AMAX, typename Load>
+__device__ __forceinline__ void small_fold_core(const IqnArgs &a, int slice, float &sq, float *pool, const SmallIo &io,
+                                                Load load, float *extra_sum) {
     __shared__ float s_S[17][SMALL_W];      // [A] = b1 row
     __shared__ float s_D[16];
     __shared__ float s_lw[16];
@@ -968,9 +978,9 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
         if (io.gb1 && tid >= 2 * SMALL_W && tid < 3 * SMALL_W) b1v = io.b1[h];
         if (slice == 0 && tid < A) b2v = io.b2[tid];
     }
-    float sA[16], dA[16];
+    float sA[AMAX], dA[AMAX];
 #pragma unroll
-    for (int aa = 0; aa < 16; ++aa) sA[aa] = dA[aa] = 0.f;
+    for (int aa = 0; aa < AMAX; ++aa) sA[aa] = dA[aa] = 0.f;
     float pb = 0.f;
     float lw = (io.extra && slice == 0 && tid < B) ? io.extra[tid] : 0.f;
 #pragma unroll 8
@@ -979,7 +989,7 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
         pb += x.y;
         const int ab = (int)a.action[b];
 #pragma unroll
-        for (int aa = 0; aa < 16; ++aa) {
+        for (int aa = 0; aa < AMAX; ++aa) {
             sA[aa] += (ab == aa) ? x.x : 0.f;
             dA[aa] += (ab == aa) ? x.z : 0.f;
         }
@@ -996,11 +1006,11 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
     for (int x0 = 0; x0 <= A; x0 += SMALL_GROUP) {
         if (x0) __syncthreads();
 #pragma unroll
-        for (int aa = 0; aa < 17; ++aa) {
+        for (int aa = 0; aa < AMAX + 1; ++aa) {
             const int x = aa - x0;                               // (aa is compile-time, x0 uniform)
             if (aa <= A && x >= 0 && x < SMALL_GROUP) {
-                pool[(x * 64 + part) * 17 + hl] = aa == A ? pb : sA[aa < 16 ? aa : 0];
-                if (hl == 0 && aa < A) pool[(x * 64 + part) * 17 + 16] = dA[aa < 16 ? aa : 0];
+                pool[(x * 64 + part) * 17 + hl] = aa == A ? pb : sA[aa < AMAX ? aa : 0];
+                if (hl == 0 && aa < A) pool[(x * 64 + part) * 17 + 16] = dA[aa < AMAX ? aa : 0];
             }
         }
         __syncthreads();
@@ -1068,6 +1078,13 @@ __device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, fl
         for (int p = 0; p < 16; ++p) l += s_lw[p];
         *extra_sum = l;
     }
+}
+
+template <typename Load>
+__device__ __forceinline__ void small_fold_block(const IqnArgs &a, int slice, float &sq, float *pool, const SmallIo &io,
+                                                 Load load, float *extra_sum) {
+    if (a.A <= 7) small_fold_core<7>(a, slice, sq, pool, io, load, extra_sum);       // (uniform)
+    else small_fold_core<16>(a, slice, sq, pool, io, load, extra_sum);
 }
 
 // IQN head: Sb / Pb / Db were left per sample by the loss; slice 0 also writes the IQN part of the total loss

@@ -281,7 +281,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.theil_coef = d.n_heads > 1 ? d.theil_coef : 0.f;
     { const char *e = getenv("PRISM_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.stamps = (unsigned long long *)ld->dbg_stamps;
-    if (!a.stamps) a.dbg &= ~8;
+    if (!a.stamps) a.dbg &= ~24;
     a.off = ld->off;
     a.params = ld->params;
     a.target_params = ld->target_params;
@@ -815,7 +815,7 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
         fill_iqn_args(ld, ia);
         TailArgs t;
         t.adam = a;
-        t.barrier = ws.ticket + 4;
+        t.barrier = reinterpret_cast<unsigned long long *>(ws.ticket + 4);
         t.rng = k.rng;
         t.inc_per = k.inc_per;
         t.inc_tau = k.inc_tau;

@@ -329,7 +329,8 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
 
 // all three in one workgroup: among equal leaves the highest t wins
 __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
-                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0, int bd = 0) {
+                                 const float2 *__restrict__ sib = nullptr, int sib_stride = 0, int bd = 0,
+                                 bool retire_idle = false) {
     if (!bd) bd = (int)blockDim.x;
     const bool active = (int)threadIdx.x < cnt;
     const int64_t cap = rp.tree_capacity;
@@ -340,6 +341,9 @@ __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, in
     tree_sib_prefetch(rp, leaf, active, levels, sib, sib_stride, sr);
     TREE_STAMP(23);
     const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, levels, lds, bd);
+    // the ranking is done (it splits its counting over up to four thread groups): from here on only the threads that
+    // carry a leaf work, and every wave still present is one more wave at each of the `levels` barriers below
+    if (retire_idle && (int)threadIdx.x >= ((cnt + 63) & ~63)) return;
     tree_write_levels(rp, leaf, p, cnt, levels, lds, sr);
 }
 
@@ -402,7 +406,8 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
             const TreePrep p = tree_write_prepare(me, leaf, val, cnt, levels, lds, bd);
             if (tid < cnt) plan_out[tid] = make_int4(__float_as_int(p.val), p.lo | (p.hi << 16), leaf, p.rank);
         } else {
-            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride, bd);   // a record is only
+            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride, bd,    // a record is only
+                             live_threads != 0 && n <= pass);
         }                                                                                      // valid for one pass
         if (base == 0 && tid == 0) {
             float mm = old_max;                                 // (s_red was published before the first barrier)

@@ -384,21 +384,30 @@ __device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int 
 }
 
 // Grid-wide barrier for a launch whose workgroups are ALL resident at once (the host checks the occupancy before it
-// picks a kernel that calls this).  Publish: every wave drains its own stores, the workgroup meets, one lane writes the
-// L2 back (release), counts the workgroup in and -- unless it was the last to arrive -- polls the counter past the L2
-// (agent scope) until all `n` arrived, then invalidates (acquire) before anyone reads what the others wrote.
-// The counter is NOT reset here (that would put one more memory round trip on every workgroup's path): the caller
-// zeroes it once every workgroup is known to be past the barrier (the tail does it with its last-finisher ticket).
-__device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int n) {
+// picks a kernel that calls this), in two halves so that the caller can put loads between them.  *bar counts arrivals
+// over ALL launches and is never reset (64-bit: never wraps): a workgroup that drew ticket `old` belongs to launch
+// old / n, which is through when the count reaches (old / n + 1) * n -- no second atomic, no reset, no generation word.
+//   arrive: every wave drains its own stores, the workgroup meets, one lane writes the L2 back (release) and draws
+//           its ticket (the atomic is only ISSUED here);
+//   wait:   unless it was the last to arrive, that lane polls the counter past the L2 (agent scope).
+// There is NO acquire: what a workgroup reads of the others' data behind the barrier it must read with agent-scope
+// loads (they do not stop at this XCD's L2) -- one cache invalidation less on everybody's path.
+__device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long long *bar) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    unsigned long long old = 0;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(ctr, 1u) != n - 1)
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        old = atomicAdd(bar, 1ull);
+    }
+    return old;
+}
+__device__ __forceinline__ void grid_barrier_wait(unsigned long long *bar, unsigned long long old, unsigned int n) {
+    if (threadIdx.x == 0) {
+        const unsigned long long target = (old / n + 1ull) * n;
+        if (old + 1ull < target)
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
 }
@@ -406,7 +415,7 @@ __device__ __forceinline__ void grid_barrier(unsigned int *ctr, unsigned int n) 
 // the clip + Adam half of the step when it rides in the post launch (single GPU: nothing sits between the two)
 struct TailArgs {
     AdamArgs adam;
-    unsigned int *barrier;     // [2] arrivals, departures
+    unsigned long long *barrier;   // [1] arrivals, cumulative over all launches
     uint64_t *rng;             // device RNG counters {PER draws, tau draws} advanced once per step (or NULL)
     uint64_t inc_per, inc_tau;
 };
@@ -423,12 +432,13 @@ struct TailShare {
 };
 
 // Clip + Adam behind the grid barrier (1024 threads).  Everything that does not depend on the other workgroups is
-// requested or computed BEFORE the barrier and lands while the workgroup waits in it: the thread's parameter / moment
-// vectors and the float64 bias corrections (another wave than the one that polls).  Behind it: the norm partials (and
+// requested or computed between the barrier's two halves and lands while the workgroup waits: the thread's parameter /
+// moment vectors (issued AFTER the arrival ticket -- memory operations of a wave return in order, a ticket queued behind
+// them would wait for them) and the float64 bias corrections (another wave than the one that polls).  Behind it: the norm partials (and
 // the gradient where it is not owned), the 256-lane fold every launch shape uses, the update.  Bit-identical to
 // clip_adam_block.
-__device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned int *barrier, int n_role, const TailShare &sh,
-                                               unsigned long long *st) {
+__device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long long *barrier, int n_role, const TailShare &sh,
+                                               int64_t step_now, unsigned long long *st) {
     auto stamp = [&](int k) {
         if (st && threadIdx.x == 0) {
             st[(size_t)blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
@@ -438,6 +448,7 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned int *
     __shared__ float s_red[256];
     __shared__ float s_c[4];
     const int tid = threadIdx.x;
+    const unsigned long long ticket = grid_barrier_arrive(barrier);
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0;
     if (sh.have) {
         p0 = reinterpret_cast<const float4 *>(a.p)[sh.j];
@@ -445,21 +456,25 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned int *
         v0 = reinterpret_cast<const float4 *>(a.v)[sh.j];
     }
     if (tid == 64) {
-        const double t = (double)(a.step[0] + 1);
+        const double t = (double)(step_now + 1);
         const double bc1 = 1.0 - pow(a.b1, t), bc2 = 1.0 - pow(a.b2, t);
         s_c[1] = (float)(-(a.lr / bc1));
         s_c[2] = (float)sqrt(bc2);
     }
-    grid_barrier(barrier, (unsigned)n_role);
+    grid_barrier_wait(barrier, ticket, (unsigned)n_role);
     stamp(25);
+    // (everything another workgroup wrote is read at agent scope: the barrier has no acquire)
+    auto far = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto far4 = [&](int64_t i) { return make_float4(far(a.g + 4 * i), far(a.g + 4 * i + 1), far(a.g + 4 * i + 2), far(a.g + 4 * i + 3)); };
     float4 g0 = sh.g;
-    if (sh.have && !sh.own) g0 = reinterpret_cast<const float4 *>(a.g)[sh.j];
+    if (sh.have && !sh.own) g0 = far4(sh.j);
     if (tid < 256) {
         float s = 0.f;
 #pragma unroll 4
-        for (int i = tid; i < a.n_slots; i += 256) s += a.normpart[i];
+        for (int i = tid; i < a.n_slots; i += 256) s += far(a.normpart + i);
         s_red[tid] = s;
     }
+    if (blockIdx.x == 0 && tid == 64) a.step[0] = step_now + 1;        // (every workgroup read it before it arrived)
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) s_red[tid] += s_red[tid + o];
@@ -500,25 +515,16 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned int *
     if (sh.kstride)
         for (int64_t k = sh.k + sh.kstride; k < sh.nleft; k += sh.kstride) {
             const int64_t i = k < sh.s0 ? k : k + sh.cnt;
-            upd4(i, reinterpret_cast<const float4 *>(a.g)[i], reinterpret_cast<float4 *>(a.p)[i],
-                 reinterpret_cast<float4 *>(a.m)[i], reinterpret_cast<float4 *>(a.v)[i]);
+            upd4(i, far4(i), reinterpret_cast<float4 *>(a.p)[i], reinterpret_cast<float4 *>(a.m)[i],
+                 reinterpret_cast<float4 *>(a.v)[i]);
         }
     if (sh.scalar_tail && tid < (int)(a.n & 3)) {
         const int64_t i = ((a.n >> 2) << 2) + tid;
         float p = a.p[i], m = a.m[i], v = a.v[i];
-        upd(a.g[i], p, m, v);
+        upd(far(a.g + i), p, m, v);
         a.p[i] = p;
         a.m[i] = m;
         a.v[i] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int done = atomicAdd(a.ticket, 1u);
-        if (done == (unsigned)(n_role - 1)) {     // everybody is past the barrier: step counter, tickets ready for the next launch
-            a.step[0] = a.step[0] + 1;
-            *a.ticket = 0u;
-            *barrier = 0u;
-        }
     }
 }
 
@@ -542,6 +548,8 @@ template <bool WB_FULL, bool TAIL>
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb, TailArgs tl) {
     static_assert(WB_FULL || !TAIL, "the fused tail has nobody to finish a prepared writeback");
     kernarg_prefetch<sizeof(IqnArgs) + sizeof(PostWriteback) + sizeof(TailArgs)>();
+    // (fused tail) the optimizer's step count, read before anything else: workgroup 0 advances it behind the barrier
+    const int64_t step_now = TAIL ? tl.adam.step[0] : 0;
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
     constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
                                                                                        : (int)(CONV_LDS_FLOATS * sizeof(float));
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             sh.j = sh.k < sh.s0 ? sh.k : sh.k + sh.cnt;
             sh.scalar_tail = rank == 0;
         }
-        tail_clip_adam(tl.adam, tl.barrier, n_role, sh, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
+        tail_clip_adam(tl.adam, tl.barrier, n_role, sh, step_now, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
         if (!wb.enabled && tl.rng && blockIdx.x == 0 && tid == 0) {
             tl.rng[0] += tl.inc_per;
             tl.rng[1] += tl.inc_tau;

@@ -8,7 +8,7 @@
 #define STAMP_MASK 0xffffffffffull
 #endif
 __device__ unsigned long long *g_stamp;
-#define TREE_STAMP(k) do { if (threadIdx.x == 0 && g_stamp && (STAMP_MASK >> (k) & 1)) g_stamp[k] = __builtin_readcyclecounter(); } while (0)
+#define TREE_STAMP(k) do { if (threadIdx.x == 0 && g_stamp && (STAMP_MASK >> (k) & 1)) g_stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #include "common.h"
 #include "replay_kernels.h"
 using namespace prism;
@@ -29,7 +29,7 @@ int main() {
     hipMemcpy(idx, hidx.data(), B * 8, hipMemcpyHostToDevice); hipMemcpy(pr, hp.data(), B * 4, hipMemcpyHostToDevice);
     set_stamp<<<1, 1>>>(st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int threads : {256, 1024}) {
+    for (int threads : {256, 512, 1024}) {
         for (int it = 0; it < 5; ++it) per_update_kernel<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
         hipEventRecord(e0);
         for (int it = 0; it < 100; ++it) per_update_kernel<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
