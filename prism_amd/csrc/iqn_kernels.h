@@ -505,7 +505,10 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int cs = blockIdx.x % (E_DIM / 16), rc = blockIdx.x / (E_DIM / 16);
+    // workgroups go to the XCDs round-robin by index: with the row chunk in the low bits all column slices of a chunk
+    // share one XCD (8 chunks) or two (4), so an L2 holds one chunk's rows (the operands streamed all through the loop)
+    // instead of every chunk's; the weight slices (768 KB, read once) are what each L2 then holds in full
+    const int rc = blockIdx.x % a.n_chunks, cs = blockIdx.x / a.n_chunks;
     const int n = cs * 16 + j;
     const int T = a.T;
     const int R = a.B * T;
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             t += s_tap[(ww * 4 + so) * TS + i];
             if (T == 8) t += s_tap[(ww * 4 + so + 2) * TS + i];
         }
-        a.ws.convpart[(int64_t)blockIdx.x * BWD_CONV_ROW + tid] = t;
+        a.ws.convpart[(int64_t)(rc * (E_DIM / 16) + cs) * BWD_CONV_ROW + tid] = t;
     }
     PRISM_STAMP(26);
 }
