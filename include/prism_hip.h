@@ -304,8 +304,8 @@ int prism_sync_target(float *target_params, const float *params, int64_t n_param
 /* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure; off by default, adds two event records per instrumented launch).
- * Kernel ids: 0 embed, 1 tile_fwd, 2 loss, 3 bwd, 4 post, 5 front, 6 clip_adam, 7 per_sample,
- * 8 gather, 9 per_update, 10 back, 11 q_fwd, 12 q_bwd.
+ * Kernel ids: 0 embed, 1 fwd_tile, 2 loss, 3 bwd, 4 post, 5 front, 6 clip_adam, 7 per_sample,
+ * 8 gather, 9 per_update, 10 back, 11 q_loss, 12 q_bwd, 13 tail (post + clip + Adam in one launch).
  * ------------------------------------------------------------------------------------------ */
 #define PRISM_N_KERNEL_IDS 16
 /* on != 0: instrument every launch issued by the calling thread until switched off */

@@ -349,7 +349,7 @@ class HipAgent:
                     "prism_step_back")
 
     def step_fused(self, buf, eager=False, use_graph=True):
-        """Sample + update + priority writeback as five launches (prism_step_front, fwd_bwd,
+        """Sample + update + priority writeback as four launches on one GPU, five around an all-reduce (prism_step_front, fwd_bwd,
         prism_step_back); replayed from a hipGraph when the replay is full (its size is baked into
         the captured launches) and the RNG counters live on the device."""
         if self.tau_rng != "philox" or buf.mass_rng != "philox":

@@ -49,7 +49,7 @@ class Learner:
         self.timesteps_since_report = self.timesteps_since_target_model_update = 0
         self.reset_loggables()
         self.device = config.device
-        # MI355X-only knobs (not Config fields): fuse the step into five launches / replay it from a hipGraph
+        # MI355X-only knobs (not Config fields): fuse the step into four launches / replay it from a hipGraph
         self.fused = bool(getattr(config, "fused_step", True)) and \
             getattr(config, "per_mass_rng", "philox") == "philox" and getattr(config, "tau_rng", "philox") == "philox"
         self.hip_graph = bool(getattr(config, "hip_graph", True))
