@@ -81,6 +81,10 @@ constexpr int NORM_SLOTS = 2560;
 // gradient slab of one row chunk, in flat-parameter order: phi_w | phi_b | [ln1_g | ln1_b] | w1
 __host__ __device__ inline int iqn_slab_floats(int H, int ln) { return E_DIM * K_BASIS + E_DIM + (ln ? 2 * E_DIM : 0) + H * E_DIM; }
 
+struct BwdGeom {
+    int tsh, unit, units_total, nw_sh, share, cpl, spw, tpw, main_lds;
+};
+
 struct IqnArgs {
     IqnPass pass[6];
     int n_pass;
@@ -93,6 +97,7 @@ struct IqnArgs {
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
     int conv_in_bwd;       // conv-backward partials are produced by the tail of iqn_bwd_kernel (bwd_conv_ok)
+    BwdGeom bg;
     int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
     int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
@@ -485,6 +490,22 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
            9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE * 64 &&
            bwd_lds_floats(H, B, C, T, n_chunks, true) * 4 <= (H == 128 ? 76 : 152) * 1024;     // two (one) workgroups per CU
 }
+inline BwdGeom bwd_geometry(int H, int B, int C, int T, int n_chunks, bool conv) {
+    BwdGeom g;
+    g.tsh = -1;
+    for (int k = 0; k < 16; ++k)
+        if ((1 << k) == T) g.tsh = k;
+    g.unit = T > 16 ? T / 16 : 1;
+    g.units_total = (B * T / 16) / g.unit;
+    g.nw_sh = 0;
+    while ((1 << g.nw_sh) < 4 * n_chunks) ++g.nw_sh;
+    g.share = bwd_conv_share(T);
+    g.cpl = C / g.share;
+    g.spw = bwd_conv_spw(B, n_chunks);
+    g.tpw = bwd_tiles_per_wave(B, T, n_chunks);
+    g.main_lds = bwd_main_lds(H, B, C, T, n_chunks, conv);
+    return g;
+}
 #ifndef BWD_CHUNKS
 #define BWD_CHUNKS 8
 #endif
@@ -512,13 +533,9 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     const int n = cs * 16 + j;
     const int T = a.T;
     const int R = a.B * T;
-    // contiguous, balanced run of tiles per wave, in units that keep a sample's rows together
-    const int unit = T > 16 ? T / 16 : 1;
-    const int units_total = (R / 16) / unit;
-    const int gw = rc * 4 + w, nw = a.n_chunks * 4;
-    // (wave-uniform by construction; made provably so, so that tile offsets live in scalar registers)
-    const int tile_begin = __builtin_amdgcn_readfirstlane((int)(((int64_t)units_total * gw) / nw) * unit);
-    const int tiles_per_wave = __builtin_amdgcn_readfirstlane((int)(((int64_t)units_total * (gw + 1)) / nw) * unit) - tile_begin;
+    const int gw = rc * 4 + w;
+    const int tile_begin = __builtin_amdgcn_readfirstlane(((a.bg.units_total * gw) >> a.bg.nw_sh) * a.bg.unit);
+    const int tiles_per_wave = __builtin_amdgcn_readfirstlane(((a.bg.units_total * (gw + 1)) >> a.bg.nw_sh) * a.bg.unit) - tile_begin;
     const g1p P = (g1p)a.params;
     const g1p e_cur = (g1p)a.ws.e_cur;
     // the row operands are read through buffer descriptors: one loop-invariant 32-bit lane offset per stream,
@@ -541,12 +558,12 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     f32x4 *w1l = wphil + 4 * 64;                                // [q][lane]: W1[h = 16q + 4g + jj][n]
     // conv-backward taps of this lane: channels [sub * cpl, (sub + 1) * cpl) x 3 x 3
     const int C = a.C, y0 = (cs & 3) * 2;
-    const int share = bwd_conv_share(T), cpl = C / share, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
+    const int cpl = a.bg.cpl, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
     const int sub = T == 8 ? (g & 1) : g;
     // observation rows y0..y0+3 of this wave's samples: requested first thing, straight into LDS (LDS-DMA: 16 B
     // per lane, lane-linear destination, no registers); the barrier in front of the tile loop covers them
     const int ws_lo = (tile_begin * 16) / T, ws_n = n_mine ? (tiles_per_wave * 16) / T : 0;
-    const int spw = bwd_conv_spw(a.B, a.n_chunks), tpw = bwd_tiles_per_wave(a.B, T, a.n_chunks);
+    const int spw = a.bg.spw, tpw = a.bg.tpw;
     float *s_obs = smem + bwd_w_lds(H) + w * (spw * 40 * C);
     // ReLU-masked d e of every tile of this wave, consumed by the tap pass behind the tile loop (keeps the tap
     // accumulators out of the loop's register budget)
@@ -836,7 +853,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     if (!n_mine) return;
     // ---- conv-backward partial row of this block: fold lanes (16 positions, then the lane groups that
     // hold the same taps for other samples), then the four waves in fixed order
-    float *s_tap = smem + bwd_main_lds(H, a.B, C, T, a.n_chunks, true);   // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
+    float *s_tap = smem + a.bg.main_lds;   // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
     constexpr int TS = BWD_CONV_TAPS + 1;
 #pragma unroll
     for (int i = 0; i < TS; ++i) {

@@ -272,6 +272,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
     a.conv_in_bwd = conv_in_bwd(ld);
+    a.bg = bwd_geometry(a.Hi, a.B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0);
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;
     a.use_iqn = d.use_iqn;

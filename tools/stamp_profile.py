@@ -44,6 +44,9 @@ b = s[:nb, 8:13].astype(np.float64)
 print(f"bwd ({nb} workgroups):")
 for k, name in enumerate(["consts", "tile loop", "barrier", "reduce+write"]):
     print(f"   {name:24s} {np.median(b[:, k + 1] - b[:, k]):9.0f}")
+be = s[64:nb, [13, 8]].astype(np.float64)
+be = be[be[:, 0] != 0]
+if len(be): print(f"   entry -> prologue loads issued (workgroups 64..): {np.median(be[:, 1] - be[:, 0]):9.0f}")
 bend = np.where(s[:nb, 26] != 0, s[:nb, 26], s[:nb, 12]).astype(np.float64)
 bd = bend - b[:, 0]
 rl = np.where(s[:nb, 58] != 0, s[:nb, 58], s[:nb, 44]).astype(np.float64)
