@@ -28,14 +28,23 @@
 
 namespace prism {
 
-constexpr int FW_WAVES = 8;
-constexpr int FW_NT = E_DIM / 16 / FW_WAVES;     // 16-column steps per wave
+// Waves that stream.  Eight (two per SIMD, eight 16-column steps each).  The kernel also runs with twelve at width 128
+// (three per SIMD taking 6 / 5 / 5 of a SIMD's sixteen steps -- set fw_waves to 12: only the first eight go on behind the
+// stream, the others store their partial sums and end, hardware barriers only count waves that have not ended), and that
+// is SLOWER on MI355X: stream + wait for the slowest wave stays at 34.7 k ticks (8 waves: 34.5 k), the fold reads 12
+// partials, kernel 28.7 vs 27.6 us same-box A/B.  With "removing every load saves 3.5 k" this says the streamed phase is
+// bound by what one SIMD issues for a step (MFMA 24.6 k + the epilogue VALU between the chains), not by latency a third
+// wave could cover.
+constexpr int FW_ROW_WAVES = 8;
+__host__ __device__ constexpr int fw_waves(int H) { return 8; }
+__host__ __device__ constexpr int fw_threads(int H) { return 64 * fw_waves(H); }
+constexpr int FW_STEPS = E_DIM / 16;             // 16-column steps of a tile
 constexpr int FW_ZS = 17;                        // row stride of the Z tile in LDS
 
 template <int H>
 __host__ __device__ constexpr int fw_lds_floats() {
     // cos tile | tau + loss scalars | row-stat partials | K-slice partials (reused by the loss fold) | Z tile | head weight
-    return 16 * CS + 128 + 2 * FW_WAVES * 16 + FW_WAVES * 16 * (H + 4) + 16 * FW_ZS + 16 + 16 * H;
+    return 16 * CS + 128 + 2 * fw_waves(H) * 16 + fw_waves(H) * 16 * (H + 4) + 16 * FW_ZS + 16 + 16 * H;
 }
 
 // sum over the 32-lane half a lane belongs to; every lane of the half receives the total (fixed order)
@@ -59,9 +68,9 @@ struct FwRow {           // what a lane needs to know about tile row m
 };
 
 template <int H, bool LN>
-__global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
+__global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_value) {
     kernarg_prefetch<sizeof(IqnArgs)>();
-    constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128;
+    constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128, FW_WAVES = fw_waves(H), NTHREADS = fw_threads(H);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *cost = smem;                          // [16][CS] cos basis of the tile's rows
     float *rowf = cost + 16 * CS;                // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
@@ -79,13 +88,18 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
     (void)a_by_value;
     const auto *kargs = (const __attribute__((address_space(4))) IqnArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) IqnArgs &a = *kargs;      // every use below reads the argument segment
+    // which pass this tile belongs to: all tile counts are requested together and compared without branches (written as
+    // a chain of short-circuit tests it was five scalar loads each waited for and branched on in turn)
     int tile = blockIdx.x, pi = 0;
+    const int n_pass = a.n_pass;
+    int nt[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) nt[i] = a.pass[i].n_tiles;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        if (pi == i && i + 1 < a.n_pass && tile >= a.pass[i].n_tiles) {
-            tile -= a.pass[i].n_tiles;
-            pi = i + 1;
-        }
+        const bool adv = (pi == i) & (i + 1 < n_pass) & (tile >= nt[i]);
+        tile -= adv ? nt[i] : 0;
+        pi += adv ? 1 : 0;
     }
     const __attribute__((address_space(4))) IqnPass *pp = &kargs->pass[pi];
     const gcf ps_params = (gcf)pp->params, ps_wpk = (gcf)pp->wpk, ps_uv = (gcf)pp->uv;
@@ -159,15 +173,16 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
     // Every weight register is refilled for the next 16-column step right after its last use, so each
     // wave keeps one step of its stream (4 + H/16 KB) in flight at all times.
     // ---------------------------------------------------------------------------------------------
-    auto stream = [&](auto phi_tag) __attribute__((always_inline)) {
+    auto stream = [&](auto phi_tag, auto nt_tag, const int step0) __attribute__((always_inline)) {
         constexpr bool PHI = decltype(phi_tag)::value;
+        constexpr int FW_NT = decltype(nt_tag)::value;      // 16-column steps of this wave, the first one being step0
         constexpr int SL = PHI ? NHT + 4 : NHT, W0 = PHI ? 4 : 0;
         typedef const f32x4 __attribute__((address_space(1))) *gcf4;      // (native vectors: a HIP float4 loaded through an
                                                                           // address-space pointer is copied via memory)
         const gcf4 wp = reinterpret_cast<gcf4>(ps_wpk) + (kind == 1 ? (size_t)hd * (H * E_DIM / 4) : (size_t)0) +
-                           (size_t)(w * FW_NT) * SL * 64 + lane;
-        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
-        const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
+                           (size_t)step0 * SL * 64 + lane;
+        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 16 * step0 + 4 * g;
+        const gcf brow = P + a.off.phi_b + 16 * step0 + 4 * g;
         // first requests: everything the first column step needs, plus what the second one needs before
         // a refill of the first one's registers could land
         // trunk weights: WD register sets, each refilled for column step nt + WD right after step nt used it
@@ -218,9 +233,8 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
             }
             lds_barrier();
             // c[m][k] = cos(tau * (k+1) * pi), two fp32 multiplies as torch does (iqn_model.py:90-92)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 512 * i, m = idx >> 6, k = idx & 63;
+            for (int idx = tid; idx < 16 * K_BASIS; idx += NTHREADS) {
+                const int m = idx >> 6, k = idx & 63;
                 const float c = cosf((rowf[m] * (float)(k + 1)) * PI_F);
                 cost[m * CS + k] = c;
                 const FwRow r = row_of(m);
@@ -305,8 +319,18 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
         }
 #undef FW_SEL
     };
-    if (kind == 1) stream(std::false_type{});
-    else stream(std::true_type{});
+    {
+        auto run = [&](auto phi_tag) __attribute__((always_inline)) {
+            if constexpr (FW_WAVES == 12) {
+                if (w < 4) stream(phi_tag, std::integral_constant<int, 6>{}, 6 * w);
+                else stream(phi_tag, std::integral_constant<int, 5>{}, 24 + 5 * (w - 4));
+            } else {
+                stream(phi_tag, std::integral_constant<int, FW_STEPS / FW_WAVES>{}, (FW_STEPS / FW_WAVES) * w);
+            }
+        };
+        if (kind == 1) run(std::false_type{});
+        else run(std::true_type{});
+    }
     PRISM_STAMP(2);
 
     // ---- fold the eight K-slices ------------------------------------------------------------------
@@ -345,6 +369,10 @@ __global__ __launch_bounds__(512) void fwd_tile_kernel(IqnArgs a_by_value) {
 #pragma unroll
     for (int ht = 0; ht < NHT; ++ht)      // accT[ht][r] = pre^T[h = 16 ht + 4 g + r][m = li]
         *reinterpret_cast<float4 *>(&part[(w * 16 + li) * HP + 16 * ht + 4 * g]) = float4{accT[ht][0], accT[ht][1], accT[ht][2], accT[ht][3]};
+    if (FW_WAVES > FW_ROW_WAVES && w >= FW_ROW_WAVES) {      // streaming-only waves: partial sums are out, done
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+    }
     lds_barrier();
     PRISM_STAMP(3);
 

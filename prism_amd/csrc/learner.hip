@@ -506,7 +506,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
                 constexpr bool LL = decltype(l)::value;
                 const size_t lds = fw_lds_floats<HH>() * sizeof(float);
                 herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
-                if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(512), lds, stream, aa);
+                if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
             });
         };
         ProfileScope ps_(K_TILE_FWD, stream);
@@ -665,7 +665,7 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
             constexpr bool LL = decltype(l)::value;
             const size_t lds = fw_lds_floats<HH>() * sizeof(float);
             herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
-            if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(512), lds, stream, aa);
+            if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
         });
     };
     a.n_pass = np;
