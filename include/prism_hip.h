@@ -222,7 +222,8 @@ typedef struct prism_learner_desc {
      * prism_step_back reduces them, clips and applies Adam in ONE launch (a grid barrier stands where the launch
      * boundary was).  ld->grads is complete only after prism_step_back then, so nothing may sit between the two
      * calls -- leave it 0 when an all-reduce does (hyper.grad_scale != 1 ignores it).  The library falls back to the
-     * separate launches by itself when the launch would not be resident at once.  Results are bit-identical. */
+     * separate launches by itself when the launch would not be resident at once or no priority writeback rides along
+     * (fused_replay unset: nothing to hide behind the barrier).  Results are bit-identical. */
     int32_t fuse_tail;
     int32_t reserved0;
     /* outputs */

@@ -448,6 +448,9 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long 
     __shared__ float s_red[256];
     __shared__ float s_c[4];
     const int tid = threadIdx.x;
+    // (the step count was requested at kernel entry; it has to have ARRIVED before this workgroup is counted in --
+    // workgroup 0 overwrites it behind the barrier)
+    asm volatile("" ::"s"((int)step_now), "s"((int)(step_now >> 32)));
     const unsigned long long ticket = grid_barrier_arrive(barrier);
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0;
     if (sh.have) {
