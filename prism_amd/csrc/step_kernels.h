@@ -206,6 +206,15 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         s_i64[0] = idx;
     }
     PRISM_STAMP(29);
+    // The sampled slot is known: every thread requests its piece of the CURRENT observation now, so that the row is
+    // on its way while thread 0 walks the n-step links (three dependent loads); the successor row can only be
+    // requested behind the walk, and lands while the first row is being convolved.  (O / 4 = 25 C <= 250 pieces.)
+    __syncthreads();
+    const int O = rp.obs_elems;     // == 100 * C
+    const float *src_obs = rp.obs + s_i64[0] * O;
+    float *d0 = f.obs + (int64_t)b * O, *d1 = f.next_obs + (int64_t)b * O;
+    float4 xc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < O / 4) xc = reinterpret_cast<const float4 *>(src_obs)[tid];
     if (tid == 0) {
         const NStepResult ns = nstep_walk(rp, idx);
         s_i64[1] = ns.last;
@@ -221,24 +230,23 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         }
     }
     PRISM_STAMP(30);
+    if (tid < O / 4) {
+        stream_store4(reinterpret_cast<float4 *>(d0) + tid, xc);
+        reinterpret_cast<float4 *>(s_obs[0])[tid] = xc;
+    }
     __syncthreads();
     // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
     if (f.use_per && tid >= 64 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity))
         reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
-    const int O = rp.obs_elems;     // == 100 * C
-    const float *src_obs = rp.obs + s_i64[0] * O;
     const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
-    float *d0 = f.obs + (int64_t)b * O, *d1 = f.next_obs + (int64_t)b * O;
-    for (int k = tid; k < O / 4; k += 256) {
-        const float4 x = reinterpret_cast<const float4 *>(src_obs)[k];
-        const float4 y = reinterpret_cast<const float4 *>(src_next)[k];
-        stream_store4(reinterpret_cast<float4 *>(d0) + k, x);
-        stream_store4(reinterpret_cast<float4 *>(d1) + k, y);
-        reinterpret_cast<float4 *>(s_obs[0])[k] = x;
-        reinterpret_cast<float4 *>(s_obs[1])[k] = y;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < O / 4) xn = reinterpret_cast<const float4 *>(src_next)[tid];
+    conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);
+    if (tid < O / 4) {
+        stream_store4(reinterpret_cast<float4 *>(d1) + tid, xn);
+        reinterpret_cast<float4 *>(s_obs[1])[tid] = xn;
     }
     __syncthreads();
-    conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);
     conv_embed_rows(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
     PRISM_STAMP(31);
 }
