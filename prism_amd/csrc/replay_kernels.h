@@ -651,25 +651,25 @@ __device__ __forceinline__ NStepResult nstep_walk(const prism_replay_desc &rp, i
     NStepResult r;
     int64_t cur = first;
     double ret = 0.0, gamma = 1.0;
+    // reward, flags AND link of a slot are requested together: one memory round trip per hop (asking for the link only
+    // once the flags say it is wanted made it two)
+    uint32_t f = 0;
     for (int k = 0; k < rp.n_step; ++k) {
-        ret += (double)rp.reward[cur] * rp.gammas[k];
+        const float rw = rp.reward[cur];
+        const int32_t nx = rp.link[cur];
+        f = rp.flags[cur];
+        ret += (double)rw * rp.gammas[k];
         gamma = rp.gammas[k + 1];
         const bool incomplete = (k != rp.n_step - 1);
-        const uint32_t f = rp.flags[cur];
-        if ((f & PRISM_FLAG_HAS_NEXT) && !(f & PRISM_FLAG_TRUNC) && incomplete) {
-            const int32_t nx = rp.link[cur];
-            if (nx >= 0)
-                cur = nx;
-            else
-                break;
-        } else {
+        if ((f & PRISM_FLAG_HAS_NEXT) && !(f & PRISM_FLAG_TRUNC) && incomplete && nx >= 0)
+            cur = nx;
+        else
             break;
-        }
     }
     r.last = cur;
     r.ret = ret;
     r.gamma = gamma;
-    r.flags = rp.flags[cur];
+    r.flags = f;            // (flags of the slot the walk stopped at: the last ones read)
     return r;
 }
 
