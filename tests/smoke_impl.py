@@ -48,6 +48,19 @@ def run_smoke(dev="cuda:0", B=16, capacity=2048, verbose=True):
     last = {int(i): w for i, w in zip(idx, want)}
     for i, w in last.items():
         assert leaves[i] == w, (i, leaves[i], w)
+    # acting forward on the updated weights (Agent.forward's estimates) vs the oracle on the same quantile samples
+    from oracle.learner_ref import act_forward
+    rng = np.random.default_rng(3)
+    obs = torch.from_numpy((rng.random((3, 10, 10, 4)) < 0.1).astype(np.float32))
+    Ta = cfg.iqn_quantile_samples_per_action
+    ataus = torch.from_numpy(rng.random((Ta * 3, 1)).astype(np.float32))
+    q, dist = agent.act_estimates(obs.to(dev), taus=ataus.to(dev))
+    sd1 = {k: v.detach().cpu() for k, v in agent.model.state_dict().items()}
+    qo, do = act_forward(sd1, orc.spec, obs, ataus)
+    aerr = max(float((q.cpu() - qo).abs().max()), float((dist.cpu() - do).abs().max()))
+    assert aerr < 1e-5, f"smoke: acting estimates differ by {aerr}"
+    act = agent.forward(obs.to(dev))
+    assert tuple(act.shape) == (3,) and int(act.min()) >= 0 and int(act.max()) < 6
     if verbose:
-        print(f"smoke OK: td err {err:.2e}, param err {perr:.2e}, {len(last)} priorities written")
+        print(f"smoke OK: td err {err:.2e}, param err {perr:.2e}, {len(last)} priorities written, acting err {aerr:.2e}")
     return err, perr
