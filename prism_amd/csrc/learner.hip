@@ -440,7 +440,7 @@ static int post_max_resident() {
         int dev = 0, cus = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true>, 1024, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true, true>, 1024, 0) != hipSuccess) return 0;
         return cus * per;
     }();
     return v;
@@ -478,9 +478,14 @@ static int launch_post(const prism_learner_desc *ld, const IqnArgs &a, const Tai
     }
     TailArgs none;
     memset(&none, 0, sizeof(none));
-    if (tail) hipLaunchKernelGGL((iqn_post_kernel<true, true>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
-    else if (wb.plan) hipLaunchKernelGGL((iqn_post_kernel<false, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
-    else hipLaunchKernelGGL((iqn_post_kernel<true, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
+    // the full writer's live threads: 2 x the batch rounded up to waves (iqn_post_kernel); dense top of the tree when it may
+    const int wb_live = ld->batch <= UPD_MAX ? std::min(1024, 2 * ((ld->batch + 63) & ~63)) : 1024;
+    const bool dense = wb.enabled && tree_dense_ok(wb.rp.tree_capacity, ld->batch, wb_live);
+    if (tail && dense) hipLaunchKernelGGL((iqn_post_kernel<true, true, true>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
+    else if (tail) hipLaunchKernelGGL((iqn_post_kernel<true, true, false>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
+    else if (wb.plan) hipLaunchKernelGGL((iqn_post_kernel<false, false, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
+    else if (dense) hipLaunchKernelGGL((iqn_post_kernel<true, false, true>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
+    else hipLaunchKernelGGL((iqn_post_kernel<true, false, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
     PRISM_CHECK_LAUNCH();
     return PRISM_OK;
 }
@@ -827,8 +832,12 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
         if (rc) return rc;
         if (k.use_per) {          // prioritised replay that is not riding in the learner's launches: its own update
             const int threads = ld->batch >= 1024 ? 1024 : ((ld->batch + 127) / 128) * 128;
-            hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(threads), 0, stream, *rp, index, ld->out_td, ld->batch, alpha, eps,
-                               1);
+            if (tree_dense_ok(rp->tree_capacity, ld->batch, threads))
+                hipLaunchKernelGGL(per_update_kernel<true>, dim3(1), dim3(threads), 0, stream, *rp, index, ld->out_td, ld->batch,
+                                   alpha, eps, 1);
+            else
+                hipLaunchKernelGGL(per_update_kernel<false>, dim3(1), dim3(threads), 0, stream, *rp, index, ld->out_td, ld->batch,
+                                   alpha, eps, 1);
             PRISM_CHECK_LAUNCH();
         }
         return PRISM_OK;

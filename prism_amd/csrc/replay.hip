@@ -111,8 +111,12 @@ extern "C" int prism_per_update(const prism_replay_desc *rp, const int64_t *inde
     const int threads = batch >= 1024 ? 1024 : ((batch + 127) / 128) * 128;
     {
         ProfileScope ps_(K_PER_UPDATE, (hipStream_t)stream);
-        hipLaunchKernelGGL(per_update_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, *rp, index, priority, batch,
-                           alpha, eps, take_abs);
+        if (tree_dense_ok(rp->tree_capacity, batch, threads))
+            hipLaunchKernelGGL(per_update_kernel<true>, dim3(1), dim3(threads), 0, (hipStream_t)stream, *rp, index, priority, batch,
+                               alpha, eps, take_abs);
+        else
+            hipLaunchKernelGGL(per_update_kernel<false>, dim3(1), dim3(threads), 0, (hipStream_t)stream, *rp, index, priority,
+                               batch, alpha, eps, take_abs);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

@@ -222,18 +222,20 @@ struct TreePrep {
     int rank, lo, hi;      // position in (leaf, batch position) order; run of equal leaves [lo, hi)
     float val;             // value of the last occurrence of this leaf
 };
+template <int NL = TREE_MAX_LEVELS>      // NL: levels the walk may cover (fewer when the top of the tree is recomputed whole)
 struct SibRegs {
-    float s[TREE_MAX_LEVELS], m[TREE_MAX_LEVELS];
+    float s[NL], m[NL];
 };
 
 // `sib` (optional): sib[s * sib_stride + t] = {sum, min} of the sibling of thread t's path node at
 // level s as of entry, recorded by whoever walked those paths last (the sampling descent reads
 // both children of every path node anyway); NULL -> read them from the tree.
+template <int NL>
 __device__ __forceinline__ void tree_sib_prefetch(const prism_replay_desc &rp, int32_t leaf, bool active, int levels,
-                                                  const float2 *__restrict__ sib, int sib_stride, SibRegs &r) {
+                                                  const float2 *__restrict__ sib, int sib_stride, SibRegs<NL> &r) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+    for (int s = 0; s < NL; ++s) {
         r.s[s] = 0.f;
         r.m[s] = 0.f;
         if (s < levels && active) {
@@ -250,8 +252,11 @@ __device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t l
     const bool active = tid < cnt;
     int32_t *s_sorted = reinterpret_cast<int32_t *>(lds);               // [UPD_MAX] leaves in rank order
     float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);        // [UPD_MAX] values in rank order
-    uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials
-    char *s_keys = lds + UPD_MAX * 12;                                  // ranking keys alias the records
+    uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials (4 KB)
+    // ranking keys alias the records, BEHIND the partials: with three or four thread groups counting (1024 threads on
+    // 256 leaves or fewer) groups 2 and 3 store their counts at bytes 6144.., where the keys used to start -- while other
+    // waves were still reading them (a rare wrong rank: the one-in-fifty mismatch of the fused-vs-unfused test)
+    char *s_keys = lds + UPD_MAX * 16;
     TreePrep p;
     p.rank = levels + UPD_POS_BITS <= 32 ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_keys), s_part, bd)
                                          : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_keys), s_part, bd);
@@ -275,8 +280,9 @@ __device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t l
     return p;
 }
 
+template <int NL>
 __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, int32_t leaf, const TreePrep &p, int cnt,
-                                                  int levels, char *lds, const SibRegs &sr) {
+                                                  int levels, char *lds, const SibRegs<NL> &sr) {
     const int tid = threadIdx.x;
     const bool active = tid < cnt;
     int4 *s_rec = reinterpret_cast<int4 *>(lds + UPD_MAX * 12);         // [2][UPD_MAX]
@@ -290,9 +296,9 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
     // Every prefetched sibling value lands HERE, once, and is then laundered through an empty asm: the
     // compiler otherwise keeps "a load may still be pending" alive through the level bodies and puts an
     // s_waitcnt vmcnt(0) into each of them -- which also waits for that level's fire-and-forget store.
-    float ss[TREE_MAX_LEVELS], sm[TREE_MAX_LEVELS];
+    float ss[NL], sm[NL];
 #pragma unroll
-    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+    for (int s = 0; s < NL; ++s) {
         ss[s] = sr.s[s];
         sm[s] = sr.m[s];
         asm volatile("" : "+v"(ss[s]), "+v"(sm[s]));
@@ -300,7 +306,7 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
     lds_only_barrier();
     TREE_STAMP(5);
 #pragma unroll
-    for (int s = 0; s < TREE_MAX_LEVELS; ++s) {
+    for (int s = 0; s < NL; ++s) {
         if (s < levels) {                                       // uniform
             const int4 *buf = s_rec + (s & 1) * UPD_MAX;
             int4 *nbuf = s_rec + ((s + 1) & 1) * UPD_MAX;
@@ -327,24 +333,97 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
     }
 }
 
-// all three in one workgroup: among equal leaves the highest t wins
+// ---- the top of the tree, recomputed whole ------------------------------------------------------------------------
+// A caller whose batch fits one pass may stop the run-merging walk TREE_DENSE_LEVELS below the root -- at the level that
+// has 256 nodes -- by handing `levels - TREE_DENSE_LEVELS` to the routines above, and let ONE wave recompute everything
+// above: the 256 nodes (old values fetched by tree_dense_fetch, the touched ones replaced from the walk's
+// last records) are folded pairwise in registers, lane to lane, and all 255 nodes above them stored.  A parent is
+// left + right and min(left, right) whichever way it is reached, so the tree comes out bit for bit as from the
+// level-by-level walk -- which pays a workgroup barrier and an LDS round trip for each of those eight levels (15 k ticks
+// for 17 levels, stand-alone).  Needs levels >= TREE_DENSE_LEVELS and `nthr` >= 64 threads still running.
+constexpr int TREE_DENSE_LEVELS = 8;
+// old values of the 256-node level -> LDS without passing through registers (LDS-DMA, 16 bytes per lane: waves 0 and 1
+// fetch 128 nodes each); call once the ranking scratch is dead, with threads 0..127 present
+__device__ __forceinline__ void tree_dense_fetch(const prism_replay_desc &rp, char *lds) {
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+        const float2 *src = tree_nodes(rp) + 256 + 2 * tid;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds + (tid >> 6) * 1024), 16, 0, 0);
+    }
+}
+// `walk_levels`: levels the walk covered; its last records lie in s_rec[(walk_levels & 1)].  `lds` as for the writer
+// (the dense level is parked where the ranking keys were).
+__device__ __forceinline__ void tree_dense_finish(const prism_replay_desc &rp, int32_t leaf, int rank, int cnt, int walk_levels,
+                                                  char *lds) {
+    const int tid = threadIdx.x;
+    float2 *s_dense = reinterpret_cast<float2 *>(lds);                  // [256] old values, parked by the caller
+    const int4 *s_rec = reinterpret_cast<const int4 *>(lds + UPD_MAX * 12) + (walk_levels & 1) * UPD_MAX;
+    if (tid < cnt) {             // (every thread of a run holds the same pair: several of them may store it)
+        const int4 q = s_rec[rank];
+        s_dense[(leaf >> walk_levels) - 256] = make_float2(__int_as_float(q.x), __int_as_float(q.y));
+    }
+    lds_only_barrier();
+    if (tid < 64) {
+        auto comb = [](float2 l, float2 r) { return make_float2(l.x + r.x, l.y < r.y ? l.y : r.y); };
+        const float4 c01 = reinterpret_cast<const float4 *>(s_dense)[2 * tid];
+        const float4 c23 = reinterpret_cast<const float4 *>(s_dense)[2 * tid + 1];
+        const float2 p0 = comb(make_float2(c01.x, c01.y), make_float2(c01.z, c01.w));
+        const float2 p1 = comb(make_float2(c23.x, c23.y), make_float2(c23.z, c23.w));
+        reinterpret_cast<float4 *>(rp.tree)[64 + tid] = make_float4(p0.x, p0.y, p1.x, p1.y);      // nodes 128 + 2 tid, + 1
+        float2 v = comb(p0, p1);
+        tree_nodes(rp)[64 + tid] = v;
+        // lane to lane: after step k the lanes with their k + 1 low bits clear hold node (64 >> (k + 1)) + (lane >> (k + 1))
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            const float2 o = make_float2(__shfl_xor(v.x, 1 << k, 64), __shfl_xor(v.y, 1 << k, 64));
+            v = ((tid >> k) & 1) ? comb(o, v) : comb(v, o);
+            if ((tid & ((2 << k) - 1)) == 0) tree_nodes(rp)[(64 >> (k + 1)) + (tid >> (k + 1))] = v;
+        }
+    }
+}
+
+// all three in one workgroup: among equal leaves the highest t wins.  DENSE: the walk stops at the 256-node level and
+// tree_dense_finish recomputes the rest (the caller has checked: levels >= TREE_DENSE_LEVELS, one pass, >= 128 threads);
+// a template so that the shorter walk also carries fewer sibling registers (the hosts of this routine run 1024 threads
+// at exactly 128 registers).
+template <bool DENSE>
+__device__ __forceinline__ void block_tree_write_impl(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt,
+                                                      char *lds, const float2 *__restrict__ sib, int sib_stride, int bd,
+                                                      bool retire_idle) {
+    constexpr int NL = DENSE ? TREE_MAX_LEVELS - TREE_DENSE_LEVELS : TREE_MAX_LEVELS;
+    const bool active = (int)threadIdx.x < cnt;
+    const int64_t cap = rp.tree_capacity;
+    const int all_levels = 63 - __clzll((unsigned long long)cap);
+    const int levels = DENSE ? all_levels - TREE_DENSE_LEVELS : all_levels;        // what the walk covers
+    const int32_t leaf = active ? (int32_t)((int64_t)my_idx | cap) : (int32_t)cap;
+    TREE_STAMP(4);
+    SibRegs<NL> sr;
+    tree_sib_prefetch<NL>(rp, leaf, active, levels, sib, sib_stride, sr);
+    TREE_STAMP(23);
+    const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, all_levels, lds, bd);
+    // (requested here: the ranking scratch they go to is dead, waves 0 and 1 are still present, and the walk's nine
+    // levels hide the trip; they land before the walk stores that level itself -- every LDS read behind an LDS-DMA waits)
+    if (DENSE) tree_dense_fetch(rp, lds);
+    // the ranking is done (it splits its counting over up to four thread groups): from here on only the threads that
+    // carry a leaf work, and every wave still present is one more wave at each of the `levels` barriers below
+    if (retire_idle && (int)threadIdx.x >= ((cnt + 63) & ~63)) return;
+    tree_write_levels<NL>(rp, leaf, p, cnt, levels, lds, sr);
+    if (DENSE) tree_dense_finish(rp, leaf, p.rank, cnt, levels, lds);
+}
+// (Both forms in ONE kernel push the 1024-thread hosts over their 128 registers: the host picks the kernel instantiation,
+// tree_dense_ok below.)
 __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, int32_t my_idx, float my_val, int cnt, char *lds,
                                  const float2 *__restrict__ sib = nullptr, int sib_stride = 0, int bd = 0,
                                  bool retire_idle = false) {
     if (!bd) bd = (int)blockDim.x;
-    const bool active = (int)threadIdx.x < cnt;
-    const int64_t cap = rp.tree_capacity;
-    const int levels = 63 - __clzll((unsigned long long)cap);
-    const int32_t leaf = active ? (int32_t)((int64_t)my_idx | cap) : (int32_t)cap;
-    TREE_STAMP(4);
-    SibRegs sr;
-    tree_sib_prefetch(rp, leaf, active, levels, sib, sib_stride, sr);
-    TREE_STAMP(23);
-    const TreePrep p = tree_write_prepare(my_idx, leaf, my_val, cnt, levels, lds, bd);
-    // the ranking is done (it splits its counting over up to four thread groups): from here on only the threads that
-    // carry a leaf work, and every wave still present is one more wave at each of the `levels` barriers below
-    if (retire_idle && (int)threadIdx.x >= ((cnt + 63) & ~63)) return;
-    tree_write_levels(rp, leaf, p, cnt, levels, lds, sr);
+    block_tree_write_impl<false>(rp, my_idx, my_val, cnt, lds, sib, sib_stride, bd, retire_idle);
+}
+// host: may a single-workgroup update of `n` leaves by `threads` threads use the dense form?
+inline bool tree_dense_ok(int64_t tree_capacity, int n, int threads) {
+    int levels = 0;
+    while (((int64_t)1 << (levels + 1)) <= tree_capacity) ++levels;
+    return levels >= TREE_DENSE_LEVELS && threads >= 128 && n <= (threads < UPD_MAX ? threads : UPD_MAX);
 }
 
 // whole PrioritizedSampler.update_priority for one batch, executed by ONE workgroup (any size)
@@ -354,7 +433,7 @@ __device__ __forceinline__ void block_tree_write(const prism_replay_desc &rp, in
 // {value, lo | hi << 16, leaf, rank} per element there; per_update_finish completes the job (in a
 // later kernel, so that the two halves hide behind different neighbours).
 constexpr int PER_UPDATE_LDS_BYTES = TREE_WRITE_LDS_BYTES + 128;
-template <bool PREPARE_ONLY = false>
+template <bool PREPARE_ONLY = false, bool DENSE = false>
 __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
                                  char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0,
@@ -406,9 +485,10 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
             const TreePrep p = tree_write_prepare(me, leaf, val, cnt, levels, lds, bd);
             if (tid < cnt) plan_out[tid] = make_int4(__float_as_int(p.val), p.lo | (p.hi << 16), leaf, p.rank);
         } else {
-            block_tree_write(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride, bd,    // a record is only
-                             live_threads != 0 && n <= pass);
-        }                                                                                      // valid for one pass
+            // (a sibling record is only valid for one pass; DENSE: the host has checked that there is only one)
+            block_tree_write_impl<DENSE>(rp, me, val, cnt, lds, n <= pass ? sib : nullptr, sib_stride, bd,
+                                         live_threads != 0 && n <= pass);
+        }
         if (base == 0 && tid == 0) {
             float mm = old_max;                                 // (s_red was published before the first barrier)
             for (int w = 0; w < (bd >> 6); ++w) mm = fmaxf(mm, s_red[w]);
@@ -429,7 +509,7 @@ __device__ __forceinline__ void per_update_finish(const prism_replay_desc &rp, c
     // record state and (speculatively) the recorded siblings
     const int4 pl = active ? plan[tid] : make_int4(0, 0, (int)cap, 0);
     const unsigned int rec = sib_state ? *sib_state : 0u;
-    SibRegs sr;
+    SibRegs<TREE_MAX_LEVELS> sr;
     if (sib) tree_sib_prefetch(rp, pl.z, active, levels, sib, sib_stride, sr);
     if (!sib || rec != 1u) tree_sib_prefetch(rp, pl.z, active, levels, nullptr, 0, sr);       // uniform; rare
     TreePrep p;
@@ -441,11 +521,12 @@ __device__ __forceinline__ void per_update_finish(const prism_replay_desc &rp, c
     if (sib_state && tid == 0) *sib_state = 0u;
 }
 
+template <bool DENSE>
 static __global__ __launch_bounds__(1024) void per_update_kernel(prism_replay_desc rp, const int64_t *__restrict__ index,
                                                          const float *__restrict__ priority, int n,
                                                          float alpha, float eps, int take_abs) {
     __shared__ __attribute__((aligned(16))) char s_pool[PER_UPDATE_LDS_BYTES];
-    per_update_block(rp, index, priority, n, alpha, eps, take_abs, s_pool);
+    per_update_block<false, DENSE>(rp, index, priority, n, alpha, eps, take_abs, s_pool);
 }
 
 // rows of an insert batch -> ring slots (any number of workgroups)

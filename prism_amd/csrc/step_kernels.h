@@ -555,7 +555,7 @@ struct PostWriteback {        // optional: prism_per_update(index, |out_td|) as 
 // TAIL: the launch also clips and applies Adam (single GPU): a grid barrier after the partial norms, then every role
 // block updates its share of the flat parameter vector; the writeback block (always the full writer then) advances the
 // device RNG counters and does not take part in the barrier.
-template <bool WB_FULL, bool TAIL>
+template <bool WB_FULL, bool TAIL, bool DENSE>
 __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback wb, TailArgs tl) {
     static_assert(WB_FULL || !TAIL, "the fused tail has nobody to finish a prepared writeback");
     kernarg_prefetch<sizeof(IqnArgs) + sizeof(PostWriteback) + sizeof(TailArgs)>();
@@ -576,8 +576,8 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             // waves the batch does not need leave now (one pass: B <= 512)
             const int live = a.B <= UPD_MAX ? min(1024, 2 * ((a.B + 63) & ~63)) : 0;     // (x2: the ranking splits its count two ways)
             if (live && (int)threadIdx.x >= live) return;
-            per_update_block(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, rec == 1u ? wb.sib : nullptr,
-                             a.B, nullptr, live);
+            per_update_block<false, DENSE>(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool,
+                                           rec == 1u ? wb.sib : nullptr, a.B, nullptr, live);
             if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;  // (every thread read it before its first barrier)
         }
         if (TAIL && tl.rng && threadIdx.x == 0) {
