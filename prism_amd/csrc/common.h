@@ -76,12 +76,14 @@ __device__ __forceinline__ void kernarg_prefetch() {
         if constexpr (n == 8)                                                                                         \
             asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\t"    \
                          "s_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, 0x100\n\ts_load_dword %0, %1, 0x140\n\t" \
-                         "s_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0" : "=&s"(T) : "s"(q));             \
+                         "s_load_dword %0, %1, 0x180\n\ts_load_dword %0, %1, 0x1c0" : "=&s"(T) : "s"(q) : "memory");             \
         else if constexpr (n >= 4)                                                                                    \
             asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, 0x40\n\ts_load_dword %0, %1, 0x80\n\t"    \
-                         "s_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, %2" : "=&s"(T) : "s"(q), "n"(64 * (n - 1))); \
+                         "s_load_dword %0, %1, 0xc0\n\ts_load_dword %0, %1, %2\n\ts_load_dword %0, %1, %3\n\t"             \
+                         "s_load_dword %0, %1, %4"                                                                    \
+                         : "=&s"(T) : "s"(q), "n"(64 * (n - 3)), "n"(64 * (n - 2)), "n"(64 * (n - 1)) : "memory");      \
         else                                                                                                          \
-            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, %2" : "=&s"(T) : "s"(q), "n"(64 * (n - 1)));  \
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_load_dword %0, %1, %2" : "=&s"(T) : "s"(q), "n"(64 * (n - 1)) : "memory");  \
     }
     PRISM_KA_GROUP(t0, 0)
     PRISM_KA_GROUP(t1, 1)
@@ -89,7 +91,8 @@ __device__ __forceinline__ void kernarg_prefetch() {
     PRISM_KA_GROUP(t3, 3)
 #undef PRISM_KA_GROUP
     // the registers stay allocated until every request has landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3));
+    // ("memory": nothing the compiler counts on lgkmcnt -- LDS traffic -- may move in between: it does not know these loads)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3) : "memory");
 }
 
 // D = A(16x4) * B(4x16) + C, exact fp32 FMA chain.  Lane l supplies A[l&15][l>>4] and
