@@ -233,7 +233,9 @@ typedef struct prism_learner_desc {
     float *out_scalars;       /* [8] {total loss, mean dl*w, mean ql*w, grad norm, theil, clip coef, -, -} */
     float *dbg_z;             /* optional [ (T+T')*B*A ] quantile estimates (tests) or NULL    */
     void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][64] uint64 shader-clock stamps, else NULL */
-    void *workspace;          /* >= prism_learner_workspace_bytes()                           */
+    void *workspace;          /* >= prism_learner_workspace_bytes(), zero-filled once.  32-bit word 2 of it is the
+                                 "target set packed" flag: whoever writes target_params (prism_sync_target's caller,
+                                 a checkpoint load) stores 0 there, on the stream; the library sets it          */
     size_t workspace_bytes;
     prism_adam_hyper hyper;
 } prism_learner_desc;

@@ -501,11 +501,18 @@ class HipAgent:
             return action
         return sel.select_action(sel.generate_action_probs(dist, q))
 
+    def _target_changed(self):
+        """The target parameters were written: its stream-packed copies in the workspace are stale (word 2 of the
+        workspace, include/prism_hip.h)."""
+        if self._B is not None:
+            self.workspace.view(torch.int32)[2] = 0
+
     @torch.no_grad()
     def sync_target_model(self):
         with torch.cuda.device(self.device):
             N.check(N.lib().prism_sync_target(N.ptr(self.flat_target), N.ptr(self.flat), self.flat.numel(),
                                               N.current_stream_handle()), "prism_sync_target")
+            self._target_changed()
 
     def set_static_batch(self, batch):
         self._static_batch = batch
@@ -553,6 +560,7 @@ class HipAgent:
         with open(os.path.join(path, "state.pkl"), "rb") as f:
             state = ref_pickle.load(f)         # reference-written files name prism.agents.action_selectors.*
         self._graphs = {}                      # captured graphs bake the hyper-parameters restored here
+        self._target_changed()
         self.action_selector = state["action_selector"]
         self.eval_action_selector = state["eval_action_selector"]
         self.max_grad_norm = state["max_grad_norm"]

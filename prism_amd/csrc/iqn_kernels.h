@@ -73,8 +73,8 @@ struct IqnWs {           // workspace pointers (device)
     float *normpart;     // [NORM_SLOTS]
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
     float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
-    unsigned int *ticket;   // [8] {adam, conv, -, sibling-record state | grid barrier of the fused tail: two 64-bit
-                            // counters, arrivals and launches}, zero-initialised by the caller; the first four reset themselves
+    unsigned int *ticket;   // [8] {adam, conv, target set packed, sibling-record state | grid barrier of the fused tail:
+                            // 64-bit arrival count, -}, zero-initialised by the caller; adam / conv / sibling reset themselves
 };
 
 constexpr int NORM_SLOTS = 2560;

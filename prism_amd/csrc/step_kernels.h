@@ -29,18 +29,24 @@ __host__ __device__ inline int front_extra_blocks(const ExtraDims &d) {
     return n;
 }
 
+// The TARGET network only changes when it is synchronised: its packed copies and u/v are rebuilt only while
+// ws.ticket[2] ("target set packed") is zero -- the post launch of every update sets it, whoever writes target_params
+// (prism_sync_target's caller, a checkpoint load) clears it.  With ten Q heads that is half of this launch's blocks.
 __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float *s_red) {
     const int tid = threadIdx.x;
     const int sets = 1 + (a.has_target ? 1 : 0);
+    const bool target_done = a.has_target && a.ws.ticket[2] != 0u;
     if (a.use_iqn) {
         const int nuv = a.ln ? a.Hi / 4 : 0, npk = iqn_pack_blocks(a.Hi);
         for (int set = 0; set < sets; ++set) {
             if (x < nuv) {
+                if (set && target_done) return;
                 iqn_uv_block(a, set, x * 4 + (tid >> 6), tid & 63);
                 return;
             }
             x -= nuv;
             if (x < npk) {
+                if (set && target_done) return;
                 pack_weights_block(set ? a.target_params : a.params, a.off, a.Hi, a.ln, a.ws.wpk[set], x, tid);
                 return;
             }
@@ -53,11 +59,13 @@ __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float
     x -= hd * per_head;
     for (int set = 0; set < sets; ++set) {
         if (x < npk) {
+            if (set && target_done) return;
             pack_head_w1_block(set ? a.target_params : a.params, a.off, a.Hq, a.ln, a.ws.q_wpk[set], hd, x, tid);
             return;
         }
         x -= npk;
         if (x < nuv) {
+            if (set && target_done) return;
             q_uv_block(a, set, hd, x * 4 + (tid >> 6), tid & 63);
             return;
         }
@@ -763,6 +771,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     }
     const float t = block_sum_1024(sq, s_red);
     if (tid == 0) a.ws.normpart[blockIdx.x] = t;
+    if (blockIdx.x == 0 && tid == 0 && a.has_target) a.ws.ticket[2] = 1u;      // the front / embed launch of this update packed the target set
     PRISM_STAMP(14);
     if constexpr (TAIL) {
         const int n_role = wb.enabled ? (int)gridDim.x - 1 : (int)gridDim.x;
