@@ -202,7 +202,9 @@ extern "C" size_t prism_learner_workspace_bytes(const prism_model_dims *dims, in
     return carve_iqn(dims, batch, nullptr, nullptr, nullptr, nullptr);
 }
 
-static int check_learner(const prism_learner_desc *ld) {
+// `need_batch`: the minibatch arrays and outputs of an update must be bound (not for the acting forward, which may well
+// run before the first update)
+static int check_learner(const prism_learner_desc *ld, bool need_batch = true) {
     PRISM_CHECK_ARG(ld != nullptr, "null descriptor");
     if (iqn_supported(&ld->dims, ld->batch) != PRISM_OK) {
         set_error("prism_learner: model dims / batch not covered by the HIP kernels "
@@ -227,6 +229,7 @@ static int check_learner(const prism_learner_desc *ld) {
     PRISM_CHECK_ARG(!ld->dims.use_iqn || (ld->off.iqn_w1 >= 0 && ld->off.iqn_w2 >= 0 &&
                                           (!ld->dims.use_layer_norm || (ld->off.iqn_ln1_g >= 0 && ld->off.iqn_ln2_g >= 0))),
                     "IQN parameter offsets missing");
+    if (!need_batch) return PRISM_OK;
     PRISM_CHECK_ARG(ld->obs && ld->next_obs && ld->reward && ld->nonterminal && ld->gamma && ld->action,
                     "null batch arrays");
     PRISM_CHECK_ARG(ld->out_td && ld->out_scalars, "null outputs");
@@ -614,7 +617,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
 extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n, int32_t n_tau,
                                  const float *tau_in, uint64_t seed, uint64_t offset, float *out_z, float *out_q,
                                  prism_stream_t stream_) {
-    int rc = check_learner(ld);
+    int rc = check_learner(ld, false);
     if (rc) return rc;
     PRISM_CHECK_ARG(obs != nullptr && n >= 1 && n <= ld->batch, "n must be in [1, batch]");
     const int n_pad = (n + 15) / 16 * 16;

@@ -145,3 +145,17 @@ def test_act_forward_rejects_bad_arguments(dev):
     assert L.prism_act_forward(ctypes.byref(d), None, 4, 8, None, 1, 0, N.ptr(z), None, None) == N.PRISM_ERR_INVALID
     assert L.prism_act_forward(ctypes.byref(d), N.ptr(obs), 4, 8, None, 1, 0, None, None, None) == N.PRISM_ERR_INVALID
     assert L.prism_act_forward(ctypes.byref(d), N.ptr(obs), agent._B + 1, 8, None, 1, 0, N.ptr(z), None, None) == N.PRISM_ERR_INVALID
+
+
+def test_acting_before_the_first_update(dev):
+    """The collector acts before the learner has updated once: no minibatch is bound to the descriptor yet."""
+    from oracle.learner_ref import act_forward
+    g = H.load_case("full_small")
+    cfg, agent = build_hip_agent(g, dev)
+    obs, taus, _ = H.case_act(g)
+    q, dist = agent.act_estimates(obs.to(dev), taus=taus.to(dev))
+    sd = {k: v.cpu() for k, v in agent.model.state_dict().items()}
+    qo, do = act_forward(sd, H.spec_from_config(H.case_config(g), C=int(g["C"]), A=int(g["A"])), obs, taus)
+    np.testing.assert_allclose(q.cpu().numpy(), qo.numpy(), rtol=0, atol=TOL)
+    np.testing.assert_allclose(dist.cpu().numpy(), do.numpy(), rtol=0, atol=TOL)
+    assert tuple(agent.forward(obs.to(dev)).shape) == (obs.shape[0],)
