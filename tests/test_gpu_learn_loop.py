@@ -75,10 +75,16 @@ def _config(dev, tmp, **over):
               timesteps_per_iteration=4, timestep_limit=256 + 4 * 150, timesteps_per_report=400,
               timesteps_between_evaluations=300, target_update_period=36, checkpoint_dir=str(tmp), log_to_wandb=False)
     kw.update(over)
-    return baseline_config(kw.pop("base", 2), **kw)
+    extra = {k: kw.pop(k) for k in ("fused_step", "hip_graph") if k in kw}      # MI355X-only knobs: plain attributes
+    cfg = baseline_config(kw.pop("base", 2), **kw)
+    for k, v in extra.items():
+        setattr(cfg, k, v)
+    return cfg
 
 
-@pytest.mark.parametrize("over", [dict(), dict(use_target_network=True), dict(base=3)])
+@pytest.mark.parametrize("over", [dict(), dict(use_target_network=True), dict(base=3),
+                                  dict(base=0), dict(base=1, use_target_network=True), dict(fused_step=False),
+                                  dict(base=3, hip_graph=False)])
 def test_learn_runs_end_to_end_and_checkpoints_reload(tmp_path, over):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
