@@ -261,6 +261,7 @@ def main():
         Bsz = cfg.batch_size
         kbytes = {"step_front_kernel": Bsz * (8 * 400 + 17) + Bsz * (4 * levels + 16),
                   "step_back_kernel": 24 * P + 4 * Bsz + 2 * Bsz * (4 + 12 * levels)}
+        kbytes["step_tail_kernel"] = kbytes["step_back_kernel"]      # the fused tail: the same compulsory bytes
         traffic_all = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
