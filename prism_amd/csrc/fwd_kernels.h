@@ -251,9 +251,24 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
 #define FW_SEL(v, c) ((v)[c])
         // phi epilogue of column step `nt_e` (or the head rows' input); rolls the e / bias registers forward
         // component r of column step nt_e's input; after the last component the e registers roll forward
+        // ReLU(phi) of the rows the backward will see is saved as it is produced: 16 bytes per lane and step (the lane's
+        // four columns of its row), blocked [row / 16][column step][row][column] so that a backward workgroup finds the
+        // 16 x 16 block of its columns and tile in one kilobyte.  It saves that launch a sixth of its matrix work (the phi
+        // product it used to recompute) for 8 MB written here and read there.
+        // (Kept in registers until the stream is over -- 32 of them, which two waves per SIMD have to spare: memory
+        // operations of a wave retire in order, a store in the middle of the stream makes every later wait for a weight
+        // refill wait for the store's acknowledgement as well: +1.5 us, measured.)
+        // Width 256 has no registers left (237 -- even the pointer spills): nothing is saved there, the backward recomputes.
+        constexpr bool PH_ALL = H == 128;
+        f32x4 phs[PH_ALL ? FW_NT : 1];
+        float *const phi_dst = (PH_ALL && PHI && myrow.save >= 0)
+                                   ? a.ws.phis + ((myrow.save >> 4) * (int64_t)(E_DIM / 16) + step0) * 256 + (myrow.save & 15) * 16 + 4 * g
+                                   : nullptr;
         auto finish_x = [&](float (&dst)[4], int nt_e, int r) __attribute__((always_inline)) {
             const float ev = e4[nt_e & 1][r];
-            dst[r] = PHI ? fmaxf(pacc[r], 0.f) * ev : ev;
+            const float relu = PHI ? fmaxf(pacc[r], 0.f) : 0.f;
+            if (PHI && PH_ALL) phs[nt_e][r] = relu;
+            dst[r] = PHI ? relu * ev : ev;
             if (LN) {
                 s1 += dst[r];
                 s2 = fmaf(dst[r], dst[r], s2);
@@ -316,6 +331,10 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[r] = xn[r];
             }
+        }
+        if (PH_ALL && PHI && phi_dst) {
+#pragma unroll
+            for (int nt = 0; nt < FW_NT; ++nt) __builtin_nontemporal_store(phs[nt], reinterpret_cast<f32x4 *>(phi_dst + 256 * nt));
         }
 #undef FW_SEL
     };

@@ -56,6 +56,7 @@ struct IqnWs {           // workspace pointers (device)
     float *uv;           // [2 sets][2][Hi]: u = W1 g1, v = W1 beta1 of the online / target IQN trunk
     float *wpk[2];       // [online, target] stream-packed {phi_w, w1 * ln1_g}
     float *cosb, *mu1, *rstd1, *pre1, *xhat2, *rstd2;
+    float *phis;         // ReLU(phi) of the current-state rows for the backward: [row / 16][column / 16][16 rows][16 columns]
     float *zcur, *zon, *ztg;
     float *dq, *c1, *c2, *dpre1, *Sb, *Pb, *Db, *lossw;
     float *de_iqn;
@@ -542,6 +543,9 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     // the tile offset in a scalar register, everything else in the instruction's immediate
     const __amdgpu_buffer_rsrc_t rs_cos = __builtin_amdgcn_make_buffer_rsrc(a.ws.cosb, 0, R * K_BASIS * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dp = __builtin_amdgcn_make_buffer_rsrc(a.ws.dpre1, 0, R * H * 4, 0x00020000);
+    // ReLU(phi) as the forward tiles left it: one 16 x 16 block (1 KB, row-major) per (tile, column slice)
+    const __amdgpu_buffer_rsrc_t rs_ph = __builtin_amdgcn_make_buffer_rsrc(a.ws.phis, 0, ((R + 15) / 16) * 16 * E_DIM * 4, 0x00020000);
+    const int vo_ph = (4 * g * 16 + j) * 4;       // row 4 g (+ r), column j of the block
     const __amdgpu_buffer_rsrc_t rs_mu = __builtin_amdgcn_make_buffer_rsrc(a.ws.mu1, 0, R * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rs = __builtin_amdgcn_make_buffer_rsrc(a.ws.rstd1, 0, R * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c1 = __builtin_amdgcn_make_buffer_rsrc(a.ws.c1, 0, R * 4, 0x00020000);
@@ -551,7 +555,11 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
         return __builtin_bit_cast(f32x4, v);
     };
+    // Width 128: ReLU(phi) comes saved from the forward tiles (a sixth less matrix work here).  Width 256: the forward
+    // has no registers left to keep it, the phi columns are recomputed from the saved cos basis as before.
+    constexpr bool PHI_SAVED = H == 128;
     const int vo_ca = (j * K_BASIS + 4 * g) * 4, vo_da = (j * H + 4 * g) * 4;          // row on the lane
+    (void)vo_ca;
     const int vo_cb = (4 * g * K_BASIS + 4 * j) * 4, vo_db = (4 * g * H + 4 * j) * 4;  // row on the k index
     const int vo_sc = 4 * g * 4;
     f32x4 *wphil = reinterpret_cast<f32x4 *>(smem);             // [q][lane]: Wphi[n][16q + 4g + jj]
@@ -581,10 +589,12 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     PRISM_STAMP(8);
     // ---- the workgroup's weight slices -> LDS in B-operand order -------------------------------
     {
-        // Wphi rows cs*16 .. +15 are one contiguous 4 KB run: thread t takes float4 t
-        const int jj = tid >> 4, f4 = tid & 15;
-        const f32x4 v = *reinterpret_cast<g4>(P + a.off.phi_w + (int64_t)(cs * 16 + jj) * K_BASIS + 4 * f4);
-        wphil[(f4 >> 2) * 64 + (f4 & 3) * 16 + jj] = v;
+        if (!PHI_SAVED) {
+            // Wphi rows cs*16 .. +15 are one contiguous 4 KB run: thread t takes float4 t
+            const int jj = tid >> 4, f4 = tid & 15;
+            const f32x4 v = *reinterpret_cast<g4>(P + a.off.phi_w + (int64_t)(cs * 16 + jj) * K_BASIS + 4 * f4);
+            wphil[(f4 >> 2) * 64 + (f4 & 3) * 16 + jj] = v;
+        }
         // W1[h][cs*16 .. +15]: 64 B per row; thread takes (row h, float4 c4), scatters its 4 columns
         float *w1f = reinterpret_cast<float *>(w1l);
 #pragma unroll
@@ -596,7 +606,8 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             for (int c = 0; c < 4; ++c) w1f[((q * 64 + gg * 16 + 4 * c4 + c) << 2) + jh] = x[c];
         }
     }
-    const float bphi = P[a.off.phi_b + n], g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
+    const float bphi = PHI_SAVED ? 0.f : P[a.off.phi_b + n];
+    const float g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
 
     f32x4 accWphi[4], accW1[NHT];     // accWphi[c][r']: dWphi[n = 4g + r'][k = 4j + c];  accW1[4u + c][r']: dW1[h = 16g + 4r' + 64u + c][n = j]
 #pragma unroll
@@ -607,15 +618,19 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
 
     // ---- operands of a tile ---------------------------------------------------------------------
     struct TileSet {
-        f32x4 ac[4], ad[NHT];             // row on the lane:   cos[r0 + j][16q + 4g ..], dpre1[r0 + j][16q + 4g ..]
+        f32x4 ac[PHI_SAVED ? 1 : 4];      // row on the lane:   cos[r0 + j][16q + 4g ..] (only to recompute phi)
+        f32x4 ad[NHT];                    // row on the lane:   dpre1[r0 + j][16q + 4g ..]
         f32x4 cB[4], dB[4][NU];           // row on the k index: cos[r0 + 4g + r][4j ..],  dpre1[r0 + 4g + r][64u + 4j ..]
         f32x4 mu, rs, c1, c2;
+        f32x4 ph;                         // ReLU(phi)[r0 + 4g + r][n], as saved by the forward tiles
         float ev;
     };
     auto load_rows_a = [&](TileSet &S, int ti) __attribute__((always_inline)) {
         const int r0 = (tile_begin + ti) * 16;
+        if (!PHI_SAVED) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) S.ac[q] = bload4(rs_cos, vo_ca + 64 * q, r0 * K_BASIS * 4);
+            for (int q = 0; q < 4; ++q) S.ac[PHI_SAVED ? 0 : q] = bload4(rs_cos, vo_ca + 64 * q, r0 * K_BASIS * 4);
+        }
 #pragma unroll
         for (int q = 0; q < NHT; ++q) S.ad[q] = bload4(rs_dp, vo_da + 64 * q, r0 * H * 4);
     };
@@ -637,6 +652,12 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             S.c2 = bload4(rs_c2, vo_sc, r0 * 4);
         }
         S.ev = e_cur[(int64_t)((r0 + 4 * g) / T) * E_DIM + n];
+        if (PHI_SAVED) {
+            const int so = ((tile_begin + ti) * (E_DIM / 16) + cs) * 1024;   // this tile's block of the workgroup's columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                S.ph[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ph, vo_ph + 64 * r, so, 0));
+        }
     };
     TileSet S0, S1;
     S0.mu = S0.c1 = S0.c2 = S1.mu = S1.c1 = S1.c2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -649,8 +670,10 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     __syncthreads();          // weight slices (and every wave's observation rows) are in LDS
     f32x4 wphr[4], w1r[NHT];  // DB: this lane's B operands of the phi / dX products, for the whole kernel
     if (DB) {
+        if (!PHI_SAVED) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wphr[q] = wphil[q * 64 + lane];
+            for (int q = 0; q < 4; ++q) wphr[q] = wphil[q * 64 + lane];
+        }
 #pragma unroll
         for (int q = 0; q < NHT; ++q) w1r[q] = w1l[q * 64 + lane];
     }
@@ -665,7 +688,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             load_scalars(Sn, ti + 1);
             load_rows_b(Sn, ti + 1);
         }
-        // ---- phi columns and dX columns: three independent MFMA chains interleaved -------------------
+        // ---- dX columns (and, width 256, the phi columns): independent MFMA chains interleaved -------------------
         f32x4 aphi = {bphi, bphi, bphi, bphi}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
         if (ti < 4) PRISM_LOOP_STAMP(16 + 4 * ti);
@@ -675,15 +698,15 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             if (DB) {
                 wa = w1r[2 * q];
                 wb = w1r[2 * q + 1];
-                if (q < 4) wp = wphr[q & 3];
+                if (!PHI_SAVED && q < 4) wp = wphr[q & 3];
             } else {
                 wa = w1l[(2 * q) * 64 + lane];
                 wb = w1l[(2 * q + 1) * 64 + lane];
-                if (q < 4) wp = wphil[(q & 3) * 64 + lane];
+                if (!PHI_SAVED && q < 4) wp = wphil[(q & 3) * 64 + lane];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (q < 4) aphi = mfma16(S.ac[q & 3][c], wp[c], aphi);
+                if (!PHI_SAVED && q < 4) aphi = mfma16(S.ac[PHI_SAVED ? 0 : q & 3][c], wp[c], aphi);
                 adx = mfma16(S.ad[2 * q][c], wa[c], adx);
                 adx2 = mfma16(S.ad[2 * q + 1][c], wb[c], adx2);
             }
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
         float xv = 0.f, dpp = 0.f;
         const float ev = S.ev;
         auto elementwise = [&](int r) __attribute__((always_inline)) {
-            const float phi = fmaxf(aphi[r], 0.f);          // (bias already in the accumulator)
+            const float phi = PHI_SAVED ? S.ph[r] : fmaxf(aphi[r], 0.f);      // saved by the forward / recomputed (bias in the accumulator)
             const float h0 = phi * ev;
             const float xhat = LN ? (h0 - S.mu[r]) * S.rs[r] : h0;
             xv = LN ? xhat * g1 + be1 : h0;                 // trunk input (B operand of dW1)

@@ -129,6 +129,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.wpk[0] = c.f(iqn_pack_floats((int)Hi));
     w.wpk[1] = c.f(iqn_pack_floats((int)Hi));
     w.cosb = c.f(R * K_BASIS);
+    w.phis = c.f(((R + 15) / 16) * 16 * (size_t)E_DIM);
     w.mu1 = c.f(R);
     w.rstd1 = c.f(R);
     w.pre1 = c.f(R * Hi);
