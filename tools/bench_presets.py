@@ -1,0 +1,33 @@
+"""Step rate of the reference's ablation presets on the HIP path (GPU box): python tools/bench_presets.py"""
+import contextlib, io, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from prism_amd import config as C
+from prism_amd.learner import Learner
+from prism_amd.synthetic import fill_replay
+
+CASES = {
+    "additive base (IQN, width 256, T=32, no LN, uniform replay, B=64)": (C.ADDITIVE_ABLATION_BASE_CONFIG, {}),
+    "additive + PER + n-step + LN": (C.ADDITIVE_ABLATION_BASE_CONFIG, dict(use_per=True, n_step_returns_length=3, use_layer_norm=True)),
+    "additive + IDS (10 two-layer heads of width 256)": (C.ADDITIVE_ABLATION_BASE_CONFIG,
+                                                         dict(use_ids=True, ids_n_q_head_model_layers=2, ids_n_q_heads=10,
+                                                              ids_q_head_feature_dim=256, ids_ensemble_variation_coef=0)),
+    "subtractive base (everything on)": (C.SUBTRACTIVE_ABLATION_BASE_CONFIG, {}),
+}
+for name, (base, over) in CASES.items():
+    cfg = C.derive(base, device="cuda:0", experience_replay_capacity=100_000, log_to_wandb=False, **over)
+    ln = Learner()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
+    ln.time_phases = False
+    fill_replay(ln.experience_buffer, ln.experience_buffer.capacity, seed=0)
+    for _ in range(100):
+        ln.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 1000
+    for _ in range(n):
+        ln.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{name:72s} {n / dt:9.0f} steps/s  {dt / n * 1e6:7.1f} us/step  params {ln.agent.flat.numel()}")
