@@ -31,3 +31,19 @@ for name, (base, over) in CASES.items():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{name:72s} {n / dt:9.0f} steps/s  {dt / n * 1e6:7.1f} us/step  params {ln.agent.flat.numel()}")
+    # per-kernel HIP-event times of 64 eager steps
+    import ctypes
+    from prism_amd import _native as N
+    L = N.lib()
+    ms = (ctypes.c_double * N.N_KERNEL_IDS)()
+    cnt = (ctypes.c_int64 * N.N_KERNEL_IDS)()
+    L.prism_profile_collect(ms, cnt)
+    for i in range(N.N_KERNEL_IDS):
+        ms[i], cnt[i] = 0.0, 0
+    L.prism_profile_enable(1)
+    for _ in range(64):
+        ln.step(eager=True)
+    L.prism_profile_enable(0)
+    torch.cuda.synchronize()
+    L.prism_profile_collect(ms, cnt)
+    print("      ", {L.prism_profile_kernel_name(i).decode(): round(ms[i] / cnt[i] * 1e3, 1) for i in range(N.N_KERNEL_IDS) if cnt[i]})
