@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     const int64_t cap = rp.tree_capacity;
     const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
     float wr[2][6], br[2] = {0.f, 0.f};
-    float2 tr[TOP_NODES / 256], qv = make_float2(0.f, FLT_MAX);
+    float2 tr[(TOP_NODES + 255) / 256], qv = make_float2(0.f, FLT_MAX);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int i = tid + 256 * k;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     }
     if (f.use_per) {
 #pragma unroll
-        for (int k = 0; k < TOP_NODES / 256; ++k) {
+        for (int k = 0; k < (TOP_NODES + 255) / 256; ++k) {
             const int i = tid + 256 * k;
             tr[k] = make_float2(0.f, 0.f);
             if (i < top) tr[k] = tree_nodes(rp)[i];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     int64_t idx;
     if (f.use_per) {
 #pragma unroll
-        for (int k = 0; k < TOP_NODES / 256; ++k) {
+        for (int k = 0; k < (TOP_NODES + 255) / 256; ++k) {
             const int i = tid + 256 * k;
             if (i < top) s_top[i] = tr[k];
         }
