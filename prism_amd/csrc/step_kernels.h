@@ -115,61 +115,62 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         return;
     }
     PRISM_STAMP(27);
-    // Everything that does not depend on the sampled index is requested in ONE round of loads into
-    // registers (conv weights of both networks, the tree top, the nodes of the p_sum / p_min query)
-    // and only then parked in LDS: every separate wait here is a full memory round trip.
+    // Everything that does not depend on the sampled index is requested in ONE round of loads.  Wave 0 is the sampler:
+    // its lanes fetch the tree top and the nodes of the p_sum / p_min query, park them in LDS and go on alone (a wave
+    // sees its own LDS writes without a workgroup barrier); waves 1-3 fetch the conv weights of both networks meanwhile
+    // -- those are not needed before the rows are convolved, two barriers further down.
     const float *P0 = a.params, *P1 = a.has_target ? a.target_params : a.params;
     const int nw = 16 * C * 9;
     const int64_t cap = rp.tree_capacity;
     const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
-    float wr[2][6], br[2] = {0.f, 0.f};
-    float2 tr[(TOP_NODES + 255) / 256], qv = make_float2(0.f, FLT_MAX);
+    constexpr int TOP_PER_LANE = (TOP_NODES + 63) / 64, W_PER_THREAD = 8;       // 16 * 10 * 9 = 1440 weights <= 8 * 192
+    int64_t idx;
+    if (tid >= 64) {
+        const int t = tid - 64;
+        float wr[2][W_PER_THREAD], br[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int i = tid + 256 * k;
-        wr[0][k] = wr[1][k] = 0.f;
-        if (i < nw) {
-            wr[0][k] = P0[a.off.conv_w + i];
-            wr[1][k] = P1[a.off.conv_w + i];
+        for (int k = 0; k < W_PER_THREAD; ++k) {
+            const int i = t + 192 * k;
+            wr[0][k] = wr[1][k] = 0.f;
+            if (i < nw) {
+                wr[0][k] = P0[a.off.conv_w + i];
+                wr[1][k] = P1[a.off.conv_w + i];
+            }
         }
-    }
-    if (tid < 16) {
-        br[0] = P0[a.off.conv_b + tid];
-        br[1] = P1[a.off.conv_b + tid];
-    }
-    if (f.use_per) {
+        if (t < 16) {
+            br[0] = P0[a.off.conv_b + t];
+            br[1] = P1[a.off.conv_b + t];
+        }
 #pragma unroll
-        for (int k = 0; k < (TOP_NODES + 255) / 256; ++k) {
-            const int i = tid + 256 * k;
+        for (int k = 0; k < W_PER_THREAD; ++k) {
+            const int i = t + 192 * k;
+            if (i < nw) {
+                s_w[0][conv_w_slot(i)] = wr[0][k];
+                s_w[1][conv_w_slot(i)] = wr[1][k];
+            }
+        }
+        if (t < 16) {
+            s_b[0][t] = br[0];
+            s_b[1][t] = br[1];
+        }
+    } else if (f.use_per) {
+        float2 tr[TOP_PER_LANE], qv;
+#pragma unroll
+        for (int k = 0; k < TOP_PER_LANE; ++k) {
+            const int i = tid + 64 * k;
             tr[k] = make_float2(0.f, 0.f);
             if (i < top) tr[k] = tree_nodes(rp)[i];
         }
-        qv = tree_query_fetch(tree_nodes(rp), cap, rp.capacity, f.size);
-    }
+        qv = tree_query_fetch(tree_nodes(rp), cap, rp.capacity, f.size);      // (levels < 32: lanes 0..63 cover every slot)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int i = tid + 256 * k;
-        if (i < nw) {
-            s_w[0][conv_w_slot(i)] = wr[0][k];
-            s_w[1][conv_w_slot(i)] = wr[1][k];
-        }
-    }
-    if (tid < 16) {
-        s_b[0][tid] = br[0];
-        s_b[1][tid] = br[1];
-    }
-    int64_t idx;
-    if (f.use_per) {
-#pragma unroll
-        for (int k = 0; k < (TOP_NODES + 255) / 256; ++k) {
-            const int i = tid + 256 * k;
+        for (int k = 0; k < TOP_PER_LANE; ++k) {
+            const int i = tid + 64 * k;
             if (i < top) s_top[i] = tr[k];
         }
-        if (tid < 128) {
-            s_scratch[tid] = qv.x;
-            s_scratch[128 + tid] = qv.y;
-        }
-        __syncthreads();
+        s_scratch[tid] = qv.x;
+        s_scratch[128 + tid] = qv.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
         PRISM_STAMP(24);
         if (tid == 0) {
             const float2 pq = tree_query_fold(s_scratch, cap);
