@@ -281,7 +281,6 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
     float *s_zc = lds, *s_zo = s_zc + 64 * 16, *s_zt = s_zo + 64 * 16;
     float *s_y = s_zt + 64 * 16, *s_q = s_y + 64, *s_tau = s_q + 64, *s_dq = s_tau + 64;
     float *s_acc = s_dq + 64;                     // [LOSS_WAVES][AS]
-    int &s_astar = *reinterpret_cast<int *>(s_acc + LOSS_WAVES * AS);
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
@@ -323,35 +322,41 @@ __global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
     if (tid < T) s_tau[tid] = a.tau_out[(int64_t)tid * B + b];
     __syncthreads();
     PRISM_STAMP(20);
-    if (tid == 0) {
-        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133)
-        int best = 0;
-        float bestv = 0.f;
-        for (int aa = 0; aa < A; ++aa) {
-            float s = 0.f;
-            for (int j = 0; j < Tn; ++j) s += s_zo[j * A + aa];
-            s = s / (float)Tn;
-            if (aa == 0 || s > bestv) {
-                bestv = s;
-                best = aa;
+    if (w == 0) {
+        // a* = argmax_a mean_j Zon[j][a]  (first maximum wins, iqn_model.py:129-133): lane = action, each lane adds its
+        // column in the sequential order (one thread doing all A * T' reads one after the other was a third of this
+        // kernel at T' = 32), then the first maximum over the lanes
+        float mean = 0.f;
+        {
+            const int la = lane < A ? lane : 0;
+            float sacc = 0.f;
+            for (int j = 0; j < Tn; ++j) sacc += s_zo[j * A + la];
+            mean = sacc / (float)Tn;
+        }
+        int astar = 0;
+        float bestv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), 0));
+#pragma unroll
+        for (int aa = 1; aa < 16; ++aa) {
+            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), aa));
+            if (aa < A && m > bestv) {
+                bestv = m;
+                astar = aa;
             }
         }
-        s_astar = best;
-    }
-    __syncthreads();
-    PRISM_STAMP(21);
-    if (w == 0) {
+        PRISM_STAMP(21);
         const float R = a.reward[b];
         const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + s_astar] * dg;   // separate mul and add (iqn_model.py:145)
+        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + astar] * dg;     // separate mul and add (iqn_model.py:145)
         if (lane < T) s_q[lane] = s_zc[lane * A + act];
         __builtin_amdgcn_wave_barrier();
         // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64
         float lsum = 0.f, gq = 0.f;
-        const int t_l = lane % T;
+        const bool t_pow2 = (T & (T - 1)) == 0;
+        const int tsh = 31 - __clz(T);
+        const int t_l = t_pow2 ? lane & (T - 1) : lane % T;
         const float q_l = s_q[t_l], tau_l = s_tau[t_l];
         for (int p = lane; p < T * Tn; p += 64) {
-            const int j = p / T;
+            const int j = t_pow2 ? p >> tsh : p / T;
             const float d = s_y[j] - q_l;
             const float ad = fabsf(d);
             const float hub = (ad <= kap) ? 0.5f * (d * d) : kap * (ad - 0.5f * kap);
