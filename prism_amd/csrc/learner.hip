@@ -456,7 +456,8 @@ static bool tail_fused(const prism_learner_desc *ld) {
     if (!ld->fuse_tail || ld->hyper.grad_scale != 1.0f) return false;
     // without a priority writeback riding along there is nothing for the fused launch to hide behind the barrier
     // (measured, uniform replay + one-layer DQN head: 32.7 us fused vs 30.1 us as two launches)
-    if (!(ld->fused_replay && ld->fused_replay->tree && ld->fused_index)) return false;
+    static const bool always = [] { const char *e = getenv("PRISM_FUSED_TAIL_ALWAYS"); return e && atoi(e) != 0; }();
+    if (!always && !(ld->fused_replay && ld->fused_replay->tree && ld->fused_index)) return false;
     static const bool off = [] { const char *e = getenv("PRISM_NO_FUSED_TAIL"); return e && atoi(e) != 0; }();
     if (off) return false;
     return post_block_count(ld) + 1 <= post_max_resident();
