@@ -359,6 +359,10 @@ __device__ __forceinline__ void tree_dense_finish(const prism_replay_desc &rp, i
     const int tid = threadIdx.x;
     float2 *s_dense = reinterpret_cast<float2 *>(lds);                  // [256] old values, parked by the caller
     const int4 *s_rec = reinterpret_cast<const int4 *>(lds + UPD_MAX * 12) + (walk_levels & 1) * UPD_MAX;
+    // the dense level's old values are in LDS (each fetching wave waits for its own LDS-DMA, then all meet) BEFORE any
+    // touched node is written over its old value
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_only_barrier();
     if (tid < cnt) {             // (every thread of a run holds the same pair: several of them may store it)
         const int4 q = s_rec[rank];
         s_dense[(leaf >> walk_levels) - 256] = make_float2(__int_as_float(q.x), __int_as_float(q.y));
@@ -407,7 +411,10 @@ __device__ __forceinline__ void block_tree_write_impl(const prism_replay_desc &r
     if (DENSE) tree_dense_fetch(rp, lds);
     // the ranking is done (it splits its counting over up to four thread groups): from here on only the threads that
     // carry a leaf work, and every wave still present is one more wave at each of the `levels` barriers below
-    if (retire_idle && (int)threadIdx.x >= ((cnt + 63) & ~63)) return;
+    if (retire_idle && (int)threadIdx.x >= ((cnt + 63) & ~63)) {
+        if (DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a leaving wave's own LDS-DMA has landed first)
+        return;
+    }
     tree_write_levels<NL>(rp, leaf, p, cnt, levels, lds, sr);
     if (DENSE) tree_dense_finish(rp, leaf, p.rank, cnt, levels, lds);
 }
