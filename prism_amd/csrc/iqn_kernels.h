@@ -260,8 +260,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
         }                                                                                  \
     } while (0)
 
-constexpr int LOSS_WAVES = 8;
-constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
+constexpr int LOSS_WAVES = 8;    // waves of the workgroup that evaluates one sample (16 for T >= 32: its rows are walked wave by
+                                 // wave, and with few samples per launch more threads per sample cost nothing)
+__host__ __device__ constexpr int loss_waves(int T) { return T >= 32 ? 16 : LOSS_WAVES; }
 
 // ------------------------------------------------------------------------------------------
 // loss (stand-alone form, iqn_model.py:95-201): one workgroup (8 waves) per sample, for the shapes whose
@@ -272,10 +273,11 @@ constexpr int LOSS_RPW = 8;     // rows per wave (T <= 64)
 // affine (LN) or ReLU(pre1) (no LN).
 // ------------------------------------------------------------------------------------------
 template <int H>
-__host__ __device__ constexpr int loss_lds_floats() { return 3 * 64 * 16 + 4 * 64 + LOSS_WAVES * (2 * H + 4) + 4; }
+__host__ __device__ constexpr int loss_lds_floats() { return 3 * 64 * 16 + 4 * 64 + 16 * (2 * H + 4) + 4; }
 
-template <int H, bool LN>
-__global__ __launch_bounds__(64 * LOSS_WAVES) void iqn_loss_kernel(IqnArgs a) {
+template <int H, bool LN, int LW>
+__global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) {
+    constexpr int LOSS_WAVES = LW, LOSS_RPW = 64 / LW;     // rows per wave (T <= 64)
     constexpr int KH = H / 64, AS = 2 * H + 4;
     __shared__ __attribute__((aligned(16))) float lds[loss_lds_floats<H>()];
     float *s_zc = lds, *s_zo = s_zc + 64 * 16, *s_zt = s_zo + 64 * 16;

@@ -545,7 +545,11 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     if (ld->dims.use_iqn && !a.local_loss) {
         ProfileScope ps_(K_LOSS, stream);
         dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
-            hipLaunchKernelGGL((iqn_loss_kernel<decltype(h)::value, decltype(l)::value>), dim3(B), dim3(64 * LOSS_WAVES), 0, stream, a);
+            if (loss_waves(a.T) == 16)
+                hipLaunchKernelGGL((iqn_loss_kernel<decltype(h)::value, decltype(l)::value, 16>), dim3(B), dim3(64 * 16), 0, stream, a);
+            else
+                hipLaunchKernelGGL((iqn_loss_kernel<decltype(h)::value, decltype(l)::value, LOSS_WAVES>), dim3(B),
+                                   dim3(64 * LOSS_WAVES), 0, stream, a);
         });
         PRISM_CHECK_LAUNCH();
     }
