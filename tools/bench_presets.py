@@ -14,7 +14,10 @@ CASES = {
                                                               ids_q_head_feature_dim=256, ids_ensemble_variation_coef=0)),
     "subtractive base (everything on)": (C.SUBTRACTIVE_ABLATION_BASE_CONFIG, {}),
 }
+only = sys.argv[1] if len(sys.argv) > 1 else None        # substring of a case name: run just that one
 for name, (base, over) in CASES.items():
+    if only and only not in name:
+        continue
     cfg = C.derive(base, device="cuda:0", experience_replay_capacity=100_000, log_to_wandb=False, **over)
     ln = Learner()
     with contextlib.redirect_stdout(io.StringIO()):
