@@ -40,6 +40,8 @@ extern "C" {
 #define PRISM_FLAG_HAS_NEXT 4u  /* Timestep.next is not None                                */
 
 /* device status word bits (prism_replay_desc.status) */
+#define PRISM_WS_STATUS_WORD 7             /* index of the sticky status word in prism_learner_desc.workspace (uint32) */
+#define PRISM_WS_STATUS_BARRIER_TIMEOUT 1u
 #define PRISM_STATUS_NONPOSITIVE_PSUM 1
 #define PRISM_STATUS_NONPOSITIVE_PMIN 2
 
@@ -223,7 +225,11 @@ typedef struct prism_learner_desc {
      * boundary was).  ld->grads is complete only after prism_step_back then, so nothing may sit between the two
      * calls -- leave it 0 when an all-reduce does (hyper.grad_scale != 1 ignores it).  The library falls back to the
      * separate launches by itself when the launch would not be resident at once or no priority writeback rides along
-     * (fused_replay unset: nothing to hide behind the barrier).  Results are bit-identical. */
+     * (fused_replay unset: nothing to hide behind the barrier).  Results are bit-identical.
+     * The residency proof (occupancy of the launched instantiation x CUs of the current device) assumes the process has the
+     * GPU to itself: with other processes' kernels on the device leave it 0 (or set PRISM_NO_FUSED_TAIL=1).  A barrier that
+     * is not through after 100 ms is abandoned: the workgroup sets PRISM_WS_STATUS_BARRIER_TIMEOUT in the workspace's
+     * status word and skips its update instead of spinning for ever. */
     int32_t fuse_tail;
     int32_t reserved0;
     /* outputs */
@@ -235,7 +241,9 @@ typedef struct prism_learner_desc {
     void *dbg_stamps;         /* diagnostics only (PRISM_DBG & 8): [4096][64] uint64 shader-clock stamps, else NULL */
     void *workspace;          /* >= prism_learner_workspace_bytes(), zero-filled once.  32-bit word 2 of it is the
                                  "target set packed" flag: whoever writes target_params (prism_sync_target's caller,
-                                 a checkpoint load) stores 0 there, on the stream; the library sets it          */
+                                 a checkpoint load) stores 0 there, on the stream; the library sets it.  32-bit word 7
+                                 is a sticky status word: bit 0 = a workgroup of the fused tail abandoned its grid
+                                 barrier (PRISM_WS_STATUS_BARRIER_TIMEOUT): the step that set it is incomplete     */
     size_t workspace_bytes;
     prism_adam_hyper hyper;
 } prism_learner_desc;
@@ -287,6 +295,7 @@ int prism_step_back(const prism_learner_desc *ld, const prism_replay_desc *rp, c
  *   out_z    [ceil16(n*n_tau)][A]  quantile estimates, SAMPLE-major (row = b*n_tau + t); reference layout =
  *            view(n, n_tau, A).permute(1, 0, 2)
  *   out_q    [heads][ceil16(n)][A] ensemble estimates; reference layout = [:, :n].permute(1, 2, 0)
+ *            (the single-Linear DQN head, dqn_n_model_layers = 1: heads = 1, one workgroup per observation)
  * Either output may be NULL when the model has no such part. */
 int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n, int32_t n_tau,
                       const float *tau_in, uint64_t seed, uint64_t offset, float *out_z, float *out_q,
@@ -299,6 +308,13 @@ int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n,
 int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
                      int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
                      float *out_aux, int64_t *out_action, prism_stream_t stream);
+
+/* GreedyActionSelector.generate_action_probs + select_action (prism/agents/action_selectors.py:70-83; also the greedy
+ * branch of EGreedyActionSelector, :24-45): action [n] = argmax_a mean(q_estimates[:, a, :]).  q != NULL: mean over the
+ * n_heads ensemble estimates prism_act_forward left in out_q; q == NULL: mean over the n_tau quantile estimates in z
+ * (composite_model.py:66-68, models without Q heads).  out_mean (optional) [n][A]. */
+int prism_greedy_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
+                        int32_t n_heads, int64_t *out_action, float *out_mean, prism_stream_t stream);
 
 /* Agent.sync_target_model (agent.py:149-152): target := online (device-to-device copy). */
 int prism_sync_target(float *target_params, const float *params, int64_t n_params,

@@ -15,6 +15,7 @@ PRISM_OK, PRISM_ERR_INVALID, PRISM_ERR_HIP, PRISM_ERR_UNSUPPORTED = 0, -1, -2, -
 PRISM_MAX_NSTEP = 15
 FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 STATUS_NONPOSITIVE_PSUM, STATUS_NONPOSITIVE_PMIN = 1, 2
+WS_STATUS_WORD, WS_STATUS_BARRIER_TIMEOUT = 7, 1
 
 c_i32, c_i64, c_u64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
 
@@ -95,6 +96,7 @@ SIGNATURES = {
     "prism_act_forward": (ctypes.c_int, [_P(LearnerDesc), c_vp, c_i32, c_i32, c_vp, c_u64, c_u64, c_vp, c_vp, c_vp]),
     "prism_ids_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp,
                                         c_vp, c_vp]),
+    "prism_greedy_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),

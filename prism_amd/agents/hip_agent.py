@@ -434,15 +434,14 @@ class HipAgent:
     def act_estimates(self, obs, taus=None):
         """``(q_estimates, return_distribution)`` as ``CompositeModel.forward(x, for_action=True)`` hands them to the
         action selector (composite_model.py:51-70): ``(n, A, heads)`` and ``(n_quantile_samples_per_action, n, A)``,
-        computed by the HIP forward tiles (``prism_act_forward``) on the learner's flat parameters.  ``taus``: explicit
-        quantile samples ``[T*n, 1]`` in the reference's order (parity tests).  The single-Linear DQN head
-        (``dqn_n_model_layers`` 0) has no tile form; its ``n x 1024 x A`` product stays a torch matmul on the device."""
+        computed by ``prism_act_forward`` on the learner's flat parameters (forward tiles for the IQN rows and the
+        two-layer heads, one workgroup per observation for the single-Linear DQN head).  ``taus``: explicit quantile
+        samples ``[T*n, 1]`` in the reference's order (parity tests)."""
         from prism_amd.agents.modules import _as_tensor
         obs = _as_tensor(obs, self.device).contiguous()
         dm = self.dims
         q_tiles = dm.n_heads > 0 and dm.head_layers == 2
-        if not dm.use_iqn and not q_tiles:
-            return self.model(obs, for_action=True)
+        q_rows = dm.n_heads > 0 and dm.head_layers == 1
         if self._B is None:
             self._prepare(int(self.config.batch_size))
         n, B, A = int(obs.shape[0]), self._B, dm.n_actions
@@ -454,11 +453,12 @@ class HipAgent:
                                         taus.view(-1, n)[:, i:i + cap].reshape(-1, 1)) for i in range(0, n, cap)]
             q = torch.cat([p[0] for p in parts], dim=0) if parts[0][0] is not None else None
             dist = torch.cat([p[1] for p in parts], dim=1) if parts[0][1] is not None else None
+            self._act_raw = None          # (describes the last piece only: nobody may select from it)
             return q, dist
         T = int(self.model.distribution_model.n_quantile_samples_per_action) if dm.use_iqn else 0
         n_pad = (n + 15) // 16 * 16
         z = torch.empty(((n * T + 15) // 16 * 16, A), device=self.device) if dm.use_iqn else None
-        qb = torch.empty((dm.n_heads, n_pad, A), device=self.device) if q_tiles else None
+        qb = torch.empty((dm.n_heads, n_pad, A), device=self.device) if (q_tiles or q_rows) else None
         if taus is None and dm.use_iqn and self.tau_rng == "torch":
             taus = torch.rand([T * n, 1], device=self.device)
         tau = None if taus is None else taus.to(self.device, torch.float32).reshape(-1).contiguous()
@@ -472,34 +472,69 @@ class HipAgent:
         dist = z[:n * T].view(n, T, A).permute(1, 0, 2) if z is not None else None
         if qb is not None:
             q = qb[:, :n].permute(1, 2, 0)
-        elif self.model.q_function_model is not None:
-            q = self.model.q_function_model(self.model.embedding_model(obs))
         else:
+            # models without Q heads (composite_model.py:66-68); the native selectors below take this mean from z themselves
             q = dist.mean(dim=0).unsqueeze(-1)
         return q, dist
 
     @torch.no_grad()
     def forward(self, obs):
-        """Agent.forward (agent.py:31-41).  Deterministic information-directed sampling is scored and arg-minned by
-        ``prism_ids_select``; every other selector reads the two small estimate tensors with its own torch code."""
+        """Agent.forward (agent.py:31-41).  Deterministic information-directed sampling (``prism_ids_select``), greedy and
+        epsilon-greedy selection (``prism_greedy_select``; the coin and the random actions come from the selector's host
+        generator exactly as in action_selectors.py:35-45) run natively on the estimate buffers; only sampled IDS
+        (``ids_use_random_samples``: ``torch.multinomial`` on torch's generator) reads them with the selector's torch code."""
+        from prism_amd.agents.action_selectors import EGreedyActionSelector, GreedyActionSelector, IDSActionSelector
+        from prism_amd.agents.modules import _as_tensor
         sel = self.eval_action_selector if self._is_eval else self.action_selector
+        obs = _as_tensor(obs, self.device).contiguous()
+        n, A = int(obs.shape[0]), self.dims.n_actions
+        if type(sel) is EGreedyActionSelector:
+            if sel.rng.uniform(0, 1) < sel.epsilon.update(n):       # one coin for the whole call (action_selectors.py:38-41)
+                return torch.as_tensor(sel.rng.randint(A, size=(n,)), dtype=torch.long).to(self.device)
+            sel = sel.greedy
+        if self._B is None:
+            self._prepare(int(self.config.batch_size))
+        cap = (self._B // 16) * 16 if (self.dims.n_heads > 0 and self.dims.head_layers == 2) else self._B
+        if n > cap:          # in pieces: every piece is selected from its own estimate buffers
+            return torch.cat([self._forward_piece(obs[i:i + cap], sel) for i in range(0, n, cap)])
+        return self._forward_piece(obs, sel)
+
+    def _forward_piece(self, obs, sel):
+        from prism_amd.agents.action_selectors import GreedyActionSelector, IDSActionSelector
         self._act_raw = None
         q, dist = self.act_estimates(obs)
-        raw = self._act_raw
-        from prism_amd.agents.action_selectors import IDSActionSelector
+        z, qb, n, n_pad, T = self._act_raw
+        A = self.dims.n_actions
+        action = torch.empty(n, dtype=torch.int64, device=self.device)
         if (type(sel) is IDSActionSelector and not sel.random_sample and sel.unsquish_function is None
-                and raw is not None and raw[0] is not None and raw[1] is not None):
-            z, qb, n, n_pad, T = raw
-            A = self.dims.n_actions
+                and z is not None and qb is not None):
             scores = torch.empty((n, A), device=self.device)
-            action = torch.empty(n, dtype=torch.int64, device=self.device)
             with torch.cuda.device(self.device):
                 N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, float(sel.lmbda),
                                                  float(sel.epsilon), float(sel.ids_rho_lower_bound), N.ptr(scores), None,
                                                  N.ptr(action), N.current_stream_handle()), "prism_ids_select")
             self._act_scores = scores
             return action
+        if type(sel) is GreedyActionSelector:
+            with torch.cuda.device(self.device):
+                N.check(N.lib().prism_greedy_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, N.ptr(action),
+                                                    None, N.current_stream_handle()), "prism_greedy_select")
+            return action
         return sel.select_action(sel.generate_action_probs(dist, q))
+
+    def check_status(self):
+        """Raise if a fused-tail grid barrier was abandoned (sticky status word of the workspace; one D2H sync).  That only
+        happens when the launch was not resident at once after all -- other processes' kernels on the same GPU -- and
+        leaves the step that hit it half applied; the agent switches the fused tail off for what follows."""
+        if self._B is None:
+            return
+        bits = int(self.workspace.view(torch.int32)[N.WS_STATUS_WORD].item())
+        if bits & N.WS_STATUS_BARRIER_TIMEOUT:
+            self.fuse_tail = False
+            self._graphs = {}
+            self.workspace.view(torch.int32)[N.WS_STATUS_WORD] = 0
+            raise RuntimeError("prism_amd: a fused-tail grid barrier timed out (is the GPU shared with another process?); "
+                               "the last steps are incomplete -- restore a checkpoint; fuse_tail is now off")
 
     def _target_changed(self):
         """The target parameters were written: its stream-packed copies in the workspace are stale (word 2 of the
@@ -537,6 +572,7 @@ class HipAgent:
 
     def save(self, directory):
         """File layout of agent.py:179-203 (reference checkpoints interchange)."""
+        self.check_status()
         path = os.path.join(directory, "agent")
         os.makedirs(path, exist_ok=True)
         torch.save(self.model.state_dict(), os.path.join(path, "model.pt"))
@@ -569,6 +605,7 @@ class HipAgent:
 
     @torch.no_grad()
     def log(self, logger):
+        self.check_status()
         logger.log_data(data=float(self._static_total_loss), group_name="Report/Losses", var_name="Total Loss")
         if self._static_distribution_loss is not None:
             logger.log_data(data=float(self._static_distribution_loss.mean()), group_name="Report/Losses",

@@ -80,4 +80,42 @@ __global__ __launch_bounds__(64) void ids_score_kernel(IdsArgs k) {
     if (lane == 0) k.action[b] = best;
 }
 
+// Greedy arg-max of the mean action values (GreedyActionSelector, /root/reference/prism/agents/action_selectors.py:70-83:
+// q_estimates.mean(dim=-1).argmax(dim=-1)): the ensemble mean over the heads when the model has Q heads, else the mean of
+// the T quantile samples (composite_model.py:66-68: q_estimates = return_distribution.mean(dim=0)).  One wave per
+// observation, lane = action, sums in index order, first maximum wins (torch.argmax).
+struct GreedyArgs {
+    const float *z;      // [n][T][A] or NULL
+    const float *q;      // [heads][n_pad][A] or NULL
+    int n, n_pad, T, A, heads;
+    int64_t *action;     // [n]
+    float *mean;         // optional [n][A]
+};
+
+__global__ __launch_bounds__(64) void greedy_select_kernel(GreedyArgs k) {
+    const int b = blockIdx.x, lane = threadIdx.x, A = k.A;
+    float m = -INFINITY;
+    if (lane < A) {
+        float s = 0.f;
+        if (k.q) {
+            for (int h = 0; h < k.heads; ++h) s += k.q[((int64_t)h * k.n_pad + b) * A + lane];
+            m = s / (float)k.heads;
+        } else {
+            for (int t = 0; t < k.T; ++t) s += k.z[((int64_t)b * k.T + t) * A + lane];
+            m = s / (float)k.T;
+        }
+        if (k.mean) k.mean[(int64_t)b * A + lane] = m;
+    }
+    int best = 0;
+    float bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0));
+    for (int a = 1; a < A; ++a) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), a));
+        if (v > bv) {
+            bv = v;
+            best = a;
+        }
+    }
+    if (lane == 0) k.action[b] = best;
+}
+
 }  // namespace prism

@@ -95,6 +95,31 @@ __device__ __forceinline__ void kernarg_prefetch() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::"s"(t0), "s"(t1), "s"(t2), "s"(t3) : "memory");
 }
 
+// ---- LDS carve-ups, checked at compile time ------------------------------------------------------------------------
+// Every kernel that splits one LDS allocation into regions states them in ONE constexpr table -- offset, size (in the unit
+// the kernel indexes by) and the phases of the kernel in which somebody may still read or write the region -- takes its
+// pointers from that table, and static_asserts lds_layout_ok() on it: two regions that are live in a common phase must not
+// overlap, and every region must lie inside the allocation.  (Round 1 shipped a writer whose ranking partials overlapped
+// the keys they were computed from; it showed as a one-in-fifty wrong rank.  That table no longer compiles: see
+// replay_kernels.h.)  The function is plain constexpr, so launch code checks run-time-sized layouts with it as well.
+struct LdsRegion {
+    int off, size;
+    unsigned live;      // bit mask of phases
+};
+constexpr unsigned LDS_ALWAYS = ~0u;
+constexpr bool lds_overlap(const LdsRegion &a, const LdsRegion &b) {
+    return (a.live & b.live) != 0u && a.size > 0 && b.size > 0 && a.off < b.off + b.size && b.off < a.off + a.size;
+}
+template <int N>
+constexpr bool lds_layout_ok(const LdsRegion (&r)[N], int total) {
+    for (int i = 0; i < N; ++i) {
+        if (r[i].off < 0 || r[i].size < 0 || r[i].off + r[i].size > total) return false;
+        for (int j = i + 1; j < N; ++j)
+            if (lds_overlap(r[i], r[j])) return false;
+    }
+    return true;
+}
+
 // D = A(16x4) * B(4x16) + C, exact fp32 FMA chain.  Lane l supplies A[l&15][l>>4] and
 // B[l>>4][l&15]; D[row = 4*(l>>4) + r][col = l&15] lands in element r.
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

@@ -41,11 +41,28 @@ __host__ __device__ constexpr int fw_threads(int H) { return 64 * fw_waves(H); }
 constexpr int FW_STEPS = E_DIM / 16;             // 16-column steps of a tile
 constexpr int FW_ZS = 17;                        // row stride of the Z tile in LDS
 
+// LDS of a forward tile (floats): cos tile | tau + loss scalars | row-stat partials | K-slice partials | Z tile | head
+// weight; the loss of a mixed tile reuses the (folded, dead) K-slice partials for its two per-row products.
+// Phases: STREAM = prologue + streamed products, ROWS = fold / LayerNorm / head, LOSS = kind-2 tail.
 template <int H>
-__host__ __device__ constexpr int fw_lds_floats() {
-    // cos tile | tau + loss scalars | row-stat partials | K-slice partials (reused by the loss fold) | Z tile | head weight
-    return 16 * CS + 128 + 2 * fw_waves(H) * 16 + fw_waves(H) * 16 * (H + 4) + 16 * FW_ZS + 16 + 16 * H;
-}
+struct FwLds {
+    static constexpr int W = fw_waves(H), HP = H + 4;
+    static constexpr unsigned STREAM = 1u, ROWS = 2u, LOSS = 4u;
+    static constexpr LdsRegion COST{0, 16 * CS, STREAM};                                    // [16][CS] cos basis of the tile's rows
+    static constexpr LdsRegion ROWF{COST.off + COST.size, 128, LDS_ALWAYS};                 // tau, loss scalars, b2 at [96, 112)
+    static constexpr LdsRegion STAT{ROWF.off + ROWF.size, 2 * W * 16, STREAM | ROWS};       // [2][waves][16 rows]
+    static constexpr LdsRegion PART{STAT.off + STAT.size, W * 16 * HP, STREAM | ROWS};      // [waves][16 rows][HP]
+    static constexpr LdsRegion ZT{PART.off + PART.size, 16 * FW_ZS + 16, ROWS | LOSS};      // [16][FW_ZS]
+    static constexpr LdsRegion W2S{ZT.off + ZT.size, 16 * H, LDS_ALWAYS};                   // [A][H] head Linear weight
+    static constexpr LdsRegion LOSS_S{PART.off, 16 * HP, LOSS};                             // [16][HP] dq * head input
+    static constexpr LdsRegion LOSS_P{PART.off + 16 * HP, 16 * HP, LOSS};                   // [16][HP] dpre1
+    static constexpr int TOTAL = W2S.off + W2S.size;
+    static constexpr LdsRegion ALL[] = {COST, ROWF, STAT, PART, ZT, W2S, LOSS_S, LOSS_P};
+    static_assert(lds_layout_ok(ALL, TOTAL), "forward tile: LDS regions live at the same time overlap");
+    static_assert(COST.off % 4 == 0 && PART.off % 4 == 0 && W2S.off % 4 == 0 && HP % 4 == 0, "16-byte accessed regions");
+};
+template <int H>
+__host__ __device__ constexpr int fw_lds_floats() { return FwLds<H>::TOTAL; }
 
 // sum over the 32-lane half a lane belongs to; every lane of the half receives the total (fixed order)
 __device__ __forceinline__ float half_sum(float v) {
@@ -72,12 +89,13 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     kernarg_prefetch<sizeof(IqnArgs)>();
     constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128, FW_WAVES = fw_waves(H), NTHREADS = fw_threads(H);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *cost = smem;                          // [16][CS] cos basis of the tile's rows
-    float *rowf = cost + 16 * CS;                // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
-    float *stat = rowf + 128;                    // [2][8 waves][16 rows] partial row sums / sums of squares
-    float *part = stat + 2 * FW_WAVES * 16;      // [8 waves][16 rows][HP] K-slice partials
-    float *zt = part + FW_WAVES * 16 * HP;       // [16][FW_ZS] quantile / Q estimates of the tile
-    float *w2s = zt + 16 * FW_ZS + 16;           // [A][H] head Linear weight; b2 in rowf[96, 112)
+    typedef FwLds<H> LD;
+    float *cost = smem + LD::COST.off;           // [16][CS] cos basis of the tile's rows
+    float *rowf = smem + LD::ROWF.off;           // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
+    float *stat = smem + LD::STAT.off;           // [2][8 waves][16 rows] partial row sums / sums of squares
+    float *part = smem + LD::PART.off;           // [8 waves][16 rows][HP] K-slice partials
+    float *zt = smem + LD::ZT.off;               // [16][FW_ZS] quantile / Q estimates of the tile
+    float *w2s = smem + LD::W2S.off;             // [A][H] head Linear weight; b2 in rowf[96, 112)
 
     // The pass this tile belongs to.  A runtime index into the by-value kernel argument would make the compiler
     // copy the whole argument into scratch (and turn every pointer in it into a flat pointer), so the pass
@@ -577,7 +595,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     lds_barrier();
     PRISM_STAMP(5);
     // head + LayerNorm(H) backward of row fm (current-state rows only; the other rows contribute nothing)
-    float *sS = part, *sP = part + 16 * HP;          // [16 rows][HP]: dq * (head input), dpre1
+    float *sS = smem + LD::LOSS_S.off, *sP = smem + LD::LOSS_P.off;      // [16 rows][HP]: dq * (head input), dpre1
     {
         const bool cur = !frow.nx;
         const float dq = cur ? s_dq[fm] : 0.f;

@@ -75,7 +75,8 @@ struct IqnWs {           // workspace pointers (device)
     float *sib;          // [TREE_MAX_LEVELS][B] float2: siblings of the sampled paths (front -> writeback)
     float *wb_plan;      // [B] int4: prepared priority writeback (post -> back)
     unsigned int *ticket;   // [8] {adam, conv, target set packed, sibling-record state | grid barrier of the fused tail:
-                            // 64-bit arrival count, -}, zero-initialised by the caller; adam / conv / sibling reset themselves
+                            // 64-bit arrival count, -, sticky status (GRID_STATUS_*)}, zero-initialised by the caller;
+                            // adam / conv / sibling reset themselves
 };
 
 constexpr int NORM_SLOTS = 2560;
@@ -272,17 +273,32 @@ __host__ __device__ constexpr int loss_waves(int T) { return T >= 32 ? 16 : LOSS
 // over waves.  T, T' must divide 64.  `xhat2` holds the head Linear's input: LayerNorm output before the
 // affine (LN) or ReLU(pre1) (no LN).
 // ------------------------------------------------------------------------------------------
+// LDS of the stand-alone loss (floats): Z of the sample's rows (current / online-next / target-next), four 64-entry rows
+// (target, prediction, tau, dq), one accumulator row per wave (at most 16 waves).  Everything is live throughout.
 template <int H>
-__host__ __device__ constexpr int loss_lds_floats() { return 3 * 64 * 16 + 4 * 64 + 16 * (2 * H + 4) + 4; }
+struct LossLds {
+    static constexpr int AS = 2 * H + 4;
+    static constexpr LdsRegion ZC{0, 64 * 16, LDS_ALWAYS}, ZO{64 * 16, 64 * 16, LDS_ALWAYS}, ZT{2 * 64 * 16, 64 * 16, LDS_ALWAYS};
+    static constexpr LdsRegion Y{3 * 64 * 16, 64, LDS_ALWAYS}, Q{3 * 64 * 16 + 64, 64, LDS_ALWAYS};
+    static constexpr LdsRegion TAU{3 * 64 * 16 + 128, 64, LDS_ALWAYS}, DQ{3 * 64 * 16 + 192, 64, LDS_ALWAYS};
+    static constexpr LdsRegion ACC{3 * 64 * 16 + 256, 16 * AS, LDS_ALWAYS};
+    static constexpr int TOTAL = ACC.off + ACC.size + 4;
+    static constexpr LdsRegion ALL[] = {ZC, ZO, ZT, Y, Q, TAU, DQ, ACC};
+    static_assert(lds_layout_ok(ALL, TOTAL), "loss kernel: LDS regions overlap");
+};
+template <int H>
+__host__ __device__ constexpr int loss_lds_floats() { return LossLds<H>::TOTAL; }
 
 template <int H, bool LN, int LW>
 __global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) {
     constexpr int LOSS_WAVES = LW, LOSS_RPW = 64 / LW;     // rows per wave (T <= 64)
     constexpr int KH = H / 64, AS = 2 * H + 4;
     __shared__ __attribute__((aligned(16))) float lds[loss_lds_floats<H>()];
-    float *s_zc = lds, *s_zo = s_zc + 64 * 16, *s_zt = s_zo + 64 * 16;
-    float *s_y = s_zt + 64 * 16, *s_q = s_y + 64, *s_tau = s_q + 64, *s_dq = s_tau + 64;
-    float *s_acc = s_dq + 64;                     // [LOSS_WAVES][AS]
+    typedef LossLds<H> LD;
+    static_assert(LW <= 16 && AS == LD::AS, "one accumulator row per wave");
+    float *s_zc = lds + LD::ZC.off, *s_zo = lds + LD::ZO.off, *s_zt = lds + LD::ZT.off;
+    float *s_y = lds + LD::Y.off, *s_q = lds + LD::Q.off, *s_tau = lds + LD::TAU.off, *s_dq = lds + LD::DQ.off;
+    float *s_acc = lds + LD::ACC.off;             // [LOSS_WAVES][AS]
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
@@ -498,6 +514,40 @@ __host__ __device__ inline bool bwd_conv_ok(int use_iqn, int n_heads, int propag
            9 * C < BWD_CONV_ROW && bwd_conv_spw(B, n_chunks) * 10 * C <= BWD_CONV_PRE * 64 &&
            bwd_lds_floats(H, B, C, T, n_chunks, true) * 4 <= (H == 128 ? 76 : 152) * 1024;     // two (one) workgroups per CU
 }
+// LDS of a backward workgroup (floats).  Compile-time part: the two weight slices; the rest is sized by the launch
+// (batch, channels, T), so the host checks the whole table with lds_layout_ok() before it launches (bwd_lds_layout_ok).
+// Phases: LOOP = tile loop + conv tap pass (weight slices, each wave's observation rows and d e values), REDUCE = cross-wave
+// fold (overlays the loop's regions behind a workgroup barrier), TAPS = the conv partial fold (a region of its own).
+constexpr unsigned BW_LOOP = 1u, BW_REDUCE = 2u, BW_TAPS = 4u;
+__host__ __device__ constexpr LdsRegion bwd_wphi_region() { return LdsRegion{0, 16 * K_BASIS, BW_LOOP}; }
+__host__ __device__ constexpr LdsRegion bwd_w1_region(int H) { return LdsRegion{16 * K_BASIS, 16 * H, BW_LOOP}; }
+__host__ __device__ constexpr LdsRegion bwd_obs_region(int H, int w, int spw, int C) {
+    return LdsRegion{bwd_w_lds(H) + w * (spw * 40 * C), spw * 40 * C, BW_LOOP};
+}
+__host__ __device__ constexpr LdsRegion bwd_dcv_region(int H, int w, int spw, int C, int tpw) {
+    return LdsRegion{bwd_w_lds(H) + 4 * (spw * 40 * C) + w * tpw * 64, tpw * 64, BW_LOOP};
+}
+__host__ __device__ constexpr LdsRegion bwd_red_region(int H) { return LdsRegion{0, 4 * bwd_acc(H) * 64, BW_REDUCE}; }
+__host__ __device__ constexpr LdsRegion bwd_tap_region(int main_lds) {
+    return LdsRegion{main_lds, 4 * 4 * (BWD_CONV_TAPS + 1), BW_TAPS | BW_REDUCE | BW_LOOP};
+}
+static_assert(!lds_overlap(bwd_wphi_region(), bwd_w1_region(128)) && bwd_w1_region(256).off + bwd_w1_region(256).size == bwd_w_lds(256),
+              "backward: weight slices");
+static_assert(4 * 4 * (BWD_CONV_TAPS + 1) <= 4 * BWD_CONV_ROW, "backward: tap fold region");
+inline bool bwd_lds_layout_ok(int H, int B, int C, int T, int n_chunks, bool conv) {
+    const int spw = bwd_conv_spw(B, n_chunks), tpw = bwd_tiles_per_wave(B, T, n_chunks);
+    const int main_lds = bwd_main_lds(H, B, C, T, n_chunks, conv), total = bwd_lds_floats(H, B, C, T, n_chunks, conv);
+    LdsRegion r[12];
+    r[0] = bwd_wphi_region();
+    r[1] = bwd_w1_region(H);
+    r[2] = bwd_red_region(H);
+    for (int w = 0; w < 4; ++w) {
+        r[3 + w] = conv ? bwd_obs_region(H, w, spw, C) : LdsRegion{0, 0, 0u};
+        r[7 + w] = conv ? bwd_dcv_region(H, w, spw, C, tpw) : LdsRegion{0, 0, 0u};
+    }
+    r[11] = conv ? bwd_tap_region(main_lds) : LdsRegion{0, 0, 0u};
+    return lds_layout_ok(r, total);
+}
 inline BwdGeom bwd_geometry(int H, int B, int C, int T, int n_chunks, bool conv) {
     BwdGeom g;
     g.tsh = -1;
@@ -569,8 +619,8 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     (void)vo_ca;
     const int vo_cb = (4 * g * K_BASIS + 4 * j) * 4, vo_db = (4 * g * H + 4 * j) * 4;  // row on the k index
     const int vo_sc = 4 * g * 4;
-    f32x4 *wphil = reinterpret_cast<f32x4 *>(smem);             // [q][lane]: Wphi[n][16q + 4g + jj]
-    f32x4 *w1l = wphil + 4 * 64;                                // [q][lane]: W1[h = 16q + 4g + jj][n]
+    f32x4 *wphil = reinterpret_cast<f32x4 *>(smem + bwd_wphi_region().off);     // [q][lane]: Wphi[n][16q + 4g + jj]
+    f32x4 *w1l = reinterpret_cast<f32x4 *>(smem + bwd_w1_region(H).off);        // [q][lane]: W1[h = 16q + 4g + jj][n]
     // conv-backward taps of this lane: channels [sub * cpl, (sub + 1) * cpl) x 3 x 3
     const int C = a.C, y0 = (cs & 3) * 2;
     const int cpl = a.bg.cpl, n_mine = a.conv_in_bwd ? 9 * cpl : 0;
@@ -579,10 +629,10 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     // per lane, lane-linear destination, no registers); the barrier in front of the tile loop covers them
     const int ws_lo = (tile_begin * 16) / T, ws_n = n_mine ? (tiles_per_wave * 16) / T : 0;
     const int spw = a.bg.spw, tpw = a.bg.tpw;
-    float *s_obs = smem + bwd_w_lds(H) + w * (spw * 40 * C);
+    float *s_obs = smem + bwd_obs_region(H, w, spw, C).off;
     // ReLU-masked d e of every tile of this wave, consumed by the tap pass behind the tile loop (keeps the tap
     // accumulators out of the loop's register budget)
-    float *s_dcv = smem + bwd_w_lds(H) + 4 * (spw * 40 * C) + w * tpw * 64;
+    float *s_dcv = smem + bwd_dcv_region(H, w, spw, C, tpw).off;
 #pragma unroll
     for (int i = 0; i < BWD_CONV_PRE; ++i) {
         const int idx = lane + 64 * i;
@@ -826,7 +876,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     // ---- reduce the four waves in fixed order and write this workgroup's slab part -------------
     __syncthreads();
     PRISM_STAMP(11);
-    float *red = smem;    // [4 waves][BWD_ACC][64]
+    float *red = smem + bwd_red_region(H).off;    // [4 waves][BWD_ACC][64]
     {
         float *mine = red + (w * BWD_ACC) * 64 + lane;
 #pragma unroll
@@ -883,7 +933,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
     if (!n_mine) return;
     // ---- conv-backward partial row of this block: fold lanes (16 positions, then the lane groups that
     // hold the same taps for other samples), then the four waves in fixed order
-    float *s_tap = smem + a.bg.main_lds;   // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
+    float *s_tap = smem + bwd_tap_region(a.bg.main_lds).off;   // [4 waves][4 lane groups][TAPS + 1]  (<= 4 * BWD_CONV_ROW)
     constexpr int TS = BWD_CONV_TAPS + 1;
 #pragma unroll
     for (int i = 0; i < TS; ++i) {
@@ -920,8 +970,12 @@ constexpr int SMALL_MAX_B = 4096;
 // Work item = (sample, out channel c, in channel ci, kernel row dy): its three dx outputs share every
 // LDS operand (10 observation values + 8 gradient values per image row feed 24 MACs).
 constexpr int CONV_LDS_FLOATS = CONV_SPB * (1000 + 16 * 65) + CONV_SPB * 16 * 10 * 3 * 3;
+constexpr LdsRegion CV_OBS{0, CONV_SPB * 1000, LDS_ALWAYS}, CV_DC{CONV_SPB * 1000, CONV_SPB * 16 * 65, LDS_ALWAYS};
+constexpr LdsRegion CV_PAR{CONV_SPB * (1000 + 16 * 65), CONV_SPB * 16 * 10 * 3 * 3, LDS_ALWAYS};     // (c, ci, dy) x 3 per sample, C <= 10
+constexpr LdsRegion CV_REGIONS[] = {CV_OBS, CV_DC, CV_PAR};
+static_assert(lds_layout_ok(CV_REGIONS, CONV_LDS_FLOATS), "conv backward block: LDS regions overlap");
 __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *lds) {
-    float *s_obs = lds, *s_dc = lds + CONV_SPB * 1000, *s_par = s_dc + CONV_SPB * 16 * 65;
+    float *s_obs = lds + CV_OBS.off, *s_dc = lds + CV_DC.off, *s_par = lds + CV_PAR.off;
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const int b0 = cb * CONV_SPB, ns = min(CONV_SPB, B - b0);
 #pragma unroll 2

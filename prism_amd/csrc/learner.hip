@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
 #include <set>
 #include <type_traits>
@@ -439,28 +440,44 @@ static hipError_t set_max_lds(const void *fn, size_t bytes) {
 
 // ---- the post launch: gradient slabs / small tensors / conv fold (+ priority writeback block); with `tail` also the
 // clip + Adam update behind a grid barrier (single GPU) ------------------------------------------------------------
-static int post_max_resident() {
-    static const int v = [] {
-        int dev = 0, cus = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true, true>, 1024, 0) != hipSuccess) return 0;
-        return cus * per;
-    }();
-    return v;
+// workgroups of the fused-tail instantiation `dense` that fit the CURRENT device at once (per device: processes that
+// drive several GPUs, and per instantiation: the two forms differ in registers)
+static int post_max_resident(bool dense) {
+    static std::mutex mu;
+    static std::map<std::pair<int, bool>, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, dense});
+    if (it != cache.end()) return it->second;
+    int cus = 0, per = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    const hipError_t e = dense ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true, true>, 1024, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, iqn_post_kernel<true, true, false>, 1024, 0);
+    if (e != hipSuccess) return 0;
+    return cache[{dev, dense}] = cus * per;
 }
 
-// The fused tail needs every workgroup of the launch resident at once (it has a grid barrier) and nothing between the
-// gradient and the optimizer step (no all-reduce: grad_scale 1).
+static bool writeback_rides(const prism_learner_desc *ld) { return ld->fused_replay && ld->fused_replay->tree && ld->fused_index; }
+// the writeback block of the post launch recomputes the top of the tree whole when it may (tree_dense_finish)
+static bool post_dense(const prism_learner_desc *ld) {
+    // the full writer's live threads: 2 x the batch rounded up to waves (iqn_post_kernel)
+    const int wb_live = ld->batch <= UPD_MAX ? std::min(1024, 2 * ((ld->batch + 63) & ~63)) : 1024;
+    return writeback_rides(ld) && tree_dense_ok(ld->fused_replay->tree_capacity, ld->batch, wb_live);
+}
+
+// The fused tail needs every workgroup of the launch resident at once (it has a grid barrier; the device must not be
+// shared with other processes' kernels -- the barrier gives up after GRID_WAIT_TICKS and flags it, step_kernels.h) and
+// nothing between the gradient and the optimizer step (no all-reduce: grad_scale 1).
 static bool tail_fused(const prism_learner_desc *ld) {
     if (!ld->fuse_tail || ld->hyper.grad_scale != 1.0f) return false;
     // without a priority writeback riding along there is nothing for the fused launch to hide behind the barrier
     // (measured, uniform replay + one-layer DQN head: 32.7 us fused vs 30.1 us as two launches)
     static const bool always = [] { const char *e = getenv("PRISM_FUSED_TAIL_ALWAYS"); return e && atoi(e) != 0; }();
-    if (!always && !(ld->fused_replay && ld->fused_replay->tree && ld->fused_index)) return false;
+    if (!always && !writeback_rides(ld)) return false;
     static const bool off = [] { const char *e = getenv("PRISM_NO_FUSED_TAIL"); return e && atoi(e) != 0; }();
     if (off) return false;
-    return post_block_count(ld) + 1 <= post_max_resident();
+    return post_block_count(ld) + 1 <= post_max_resident(post_dense(ld));
 }
 
 static int launch_post(const prism_learner_desc *ld, const IqnArgs &a, const TailArgs *tail, hipStream_t stream) {
@@ -468,7 +485,7 @@ static int launch_post(const prism_learner_desc *ld, const IqnArgs &a, const Tai
     int nb = post_block_count(ld);
     PostWriteback wb;
     memset(&wb, 0, sizeof(wb));
-    if (ld->fused_replay && ld->fused_replay->tree && ld->fused_index) {
+    if (writeback_rides(ld)) {
         // TD errors are final: the priority writeback rides along as one more block of this launch
         wb.enabled = 1;
         wb.rp = *ld->fused_replay;
@@ -483,9 +500,7 @@ static int launch_post(const prism_learner_desc *ld, const IqnArgs &a, const Tai
     }
     TailArgs none;
     memset(&none, 0, sizeof(none));
-    // the full writer's live threads: 2 x the batch rounded up to waves (iqn_post_kernel); dense top of the tree when it may
-    const int wb_live = ld->batch <= UPD_MAX ? std::min(1024, 2 * ((ld->batch + 63) & ~63)) : 1024;
-    const bool dense = wb.enabled && tree_dense_ok(wb.rp.tree_capacity, ld->batch, wb_live);
+    const bool dense = post_dense(ld);
     if (tail && dense) hipLaunchKernelGGL((iqn_post_kernel<true, true, true>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
     else if (tail) hipLaunchKernelGGL((iqn_post_kernel<true, true, false>), dim3(nb), dim3(1024), 0, stream, a, wb, *tail);
     else if (wb.plan) hipLaunchKernelGGL((iqn_post_kernel<false, false, false>), dim3(nb), dim3(1024), 0, stream, a, wb, none);
@@ -565,6 +580,10 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         PRISM_CHECK_LAUNCH();
     }
     if (ld->dims.use_iqn) {
+        if (!bwd_lds_layout_ok(a.Hi, B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0)) {
+            set_error("prism_learner_fwd_bwd: internal: LDS layout of the backward kernel overlaps for this shape");
+            return PRISM_ERR_INVALID;
+        }
         ProfileScope ps_(K_BWD, stream);
         const bool db = bwd_double_buffered(a.Hi);
         dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
@@ -640,6 +659,13 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
     a.obs = a.next_obs = obs;
     hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * n + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a);
     PRISM_CHECK_LAUNCH();
+    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 1) {
+        // single-Linear DQN head: one workgroup per observation on the embeddings just written
+        PRISM_CHECK_ARG(out_q != nullptr, "Q output buffer");
+        hipLaunchKernelGGL(dqn1_act_kernel, dim3(n), dim3(256), 0, stream, a, out_q);
+        PRISM_CHECK_LAUNCH();
+        return PRISM_OK;
+    }
     a.B = n_pad;
     a.Bt = n;
     a.seed = seed;
@@ -675,7 +701,7 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
         p.kind = 1;
         a.pass[np++] = p;
     }
-    PRISM_CHECK_ARG(np > 0, "nothing to run: the single-Linear DQN head has no tile form (use the module forward)");
+    PRISM_CHECK_ARG(np > 0, "nothing to run");
     auto launch = [&](const IqnArgs &aa, int H, int tiles) {
         dispatch_hl(H, aa.ln, [&](auto h, auto l) {
             constexpr int HH = decltype(h)::value;
@@ -711,6 +737,18 @@ extern "C" int prism_ids_select(const float *z, const float *q, int32_t n, int32
     PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_tau >= 1 && n_actions >= 1 && n_actions <= 16 && n_heads >= 1, "bad sizes");
     IdsArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, lmbda, epsilon, rho_lower_bound, out_scores, out_aux, out_action};
     hipLaunchKernelGGL(ids_score_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream_, k);
+    PRISM_CHECK_LAUNCH();
+    return PRISM_OK;
+}
+
+// GreedyActionSelector (action_selectors.py:70-83) on the buffers prism_act_forward filled.
+extern "C" int prism_greedy_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
+                                   int32_t n_heads, int64_t *out_action, float *out_mean, prism_stream_t stream_) {
+    PRISM_CHECK_ARG((z || q) && out_action, "null buffers");
+    PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_actions >= 1 && n_actions <= 16, "bad sizes");
+    PRISM_CHECK_ARG(q ? n_heads >= 1 : n_tau >= 1, "bad sizes");
+    GreedyArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, out_action, out_mean};
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream_, k);
     PRISM_CHECK_LAUNCH();
     return PRISM_OK;
 }
@@ -834,6 +872,7 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
         TailArgs t;
         t.adam = a;
         t.barrier = reinterpret_cast<unsigned long long *>(ws.ticket + 4);
+        t.status = ws.ticket + 7;
         t.rng = k.rng;
         t.inc_per = k.inc_per;
         t.inc_tau = k.inc_tau;

@@ -612,6 +612,23 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
     conv_bwd_sample_row(s_tmp, s_ob, a.C, a.ws.convpart + (int64_t)b * CONV_ROW);
 }
 
+// acting forward of the one-layer head (agent.py:31-41 -> q_ensemble.py:44-48): Q values of observation b from its
+// embedding (left in ws.e_cur by the embed launch), with the routines the loss kernel uses.  out_q: [1][n_pad][A].
+__global__ __launch_bounds__(256) void dqn1_act_kernel(IqnArgs a, float *__restrict__ out_q) {
+    __shared__ __attribute__((aligned(16))) float s_x[E_DIM], s_xhat[E_DIM];
+    __shared__ float s_q[16], s_red[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool ln = a.off.h_ln1_g >= 0;
+    const float *P = a.params + a.off.head_base;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_x[tid + 256 * i] = a.ws.e_cur[(int64_t)b * E_DIM + tid + 256 * i];
+    __syncthreads();
+    float mean = 0.f, rstd = 1.f;
+    if (ln) dqn_layernorm(s_x, s_xhat, P + a.off.h_ln1_g, P + a.off.h_ln1_b, mean, rstd, s_red);
+    dqn_q_values(s_x, P + a.off.h_w1, P + a.off.h_b1, a.A, s_q, s_red);
+    if (tid < a.A) out_q[(int64_t)b * a.A + tid] = s_q[tid];
+}
+
 // post role: dW[a][n] = sum_{b: act=a} dq_b * y_b[n], db[a], and with LayerNorm dg[n] = sum_b dy_b[n] xhat_b[n],
 // dbeta[n] = sum_b dy_b[n] (dy_b = dq_b W[act_b]).  With y = g * xhat + beta this is the algebra of
 // small_fold_block with the 1024 embedding columns as "units":

@@ -165,6 +165,20 @@ constexpr int TREE_MAX_LEVELS = 24;             // tree_capacity <= 2^24 (checke
 constexpr int UPD_MAX = 512;                    // leaves per pass of the single-workgroup writer
 constexpr int UPD_POS_BITS = 9;
 constexpr int TREE_WRITE_LDS_BYTES = UPD_MAX * 8 + UPD_MAX * 4 + 2 * UPD_MAX * 16;
+// LDS of the writer (bytes).  Phases: RANK = keys are written and counted into the partials; SORT = every thread sums its
+// partials (others may still be summing theirs) and scatters leaf / value to its rank, then reads its run; WALK = records of
+// the level walk and, in the dense form, the 256-node level.  A workgroup barrier separates RANK from SORT's scatter only
+// for the keys (block_rank's second barrier), SORT from WALK for everything ("ranking scratch is dead").
+constexpr unsigned TW_RANK = 1u, TW_SORT = 2u, TW_WALK = 4u;
+constexpr LdsRegion TW_SORTED{0, UPD_MAX * 4, TW_SORT};                     // int32 [UPD_MAX] leaves in rank order
+constexpr LdsRegion TW_VAL{UPD_MAX * 4, UPD_MAX * 4, TW_SORT};              // float [UPD_MAX] values in rank order
+constexpr LdsRegion TW_PART{UPD_MAX * 8, 4 * UPD_MAX * 2, TW_RANK | TW_SORT};   // uint16 [4][UPD_MAX] ranking partials
+constexpr LdsRegion TW_KEYS{UPD_MAX * 16, UPD_MAX * 8, TW_RANK};            // uint32 / uint64 [UPD_MAX] ranking keys
+constexpr LdsRegion TW_REC{UPD_MAX * 12, 2 * UPD_MAX * 16, TW_WALK};        // int4 [2][UPD_MAX] level records
+constexpr LdsRegion TW_DENSE{0, 256 * 8, TW_WALK};                          // float2 [256] the dense level's old values
+constexpr LdsRegion TW_REGIONS[] = {TW_SORTED, TW_VAL, TW_PART, TW_KEYS, TW_REC, TW_DENSE};
+static_assert(lds_layout_ok(TW_REGIONS, TREE_WRITE_LDS_BYTES), "tree writer: LDS regions live at the same time overlap");
+static_assert(TW_KEYS.off % 16 == 0 && TW_REC.off % 16 == 0 && TW_DENSE.off % 16 == 0, "16-byte accessed regions");
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -250,13 +264,14 @@ __device__ __forceinline__ TreePrep tree_write_prepare(int32_t my_idx, int32_t l
                                                        char *lds, int bd) {
     const int tid = threadIdx.x;
     const bool active = tid < cnt;
-    int32_t *s_sorted = reinterpret_cast<int32_t *>(lds);               // [UPD_MAX] leaves in rank order
-    float *s_val = reinterpret_cast<float *>(lds + UPD_MAX * 4);        // [UPD_MAX] values in rank order
-    uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + UPD_MAX * 8); // [4][UPD_MAX] ranking partials (4 KB)
+    int32_t *s_sorted = reinterpret_cast<int32_t *>(lds + TW_SORTED.off);
+    float *s_val = reinterpret_cast<float *>(lds + TW_VAL.off);
+    uint16_t *s_part = reinterpret_cast<uint16_t *>(lds + TW_PART.off);
     // ranking keys alias the records, BEHIND the partials: with three or four thread groups counting (1024 threads on
     // 256 leaves or fewer) groups 2 and 3 store their counts at bytes 6144.., where the keys used to start -- while other
-    // waves were still reading them (a rare wrong rank: the one-in-fifty mismatch of the fused-vs-unfused test)
-    char *s_keys = lds + UPD_MAX * 16;
+    // waves were still reading them (a rare wrong rank: the one-in-fifty mismatch of the fused-vs-unfused test; with the
+    // keys at byte 6144 the static_assert on TW_REGIONS fails)
+    char *s_keys = lds + TW_KEYS.off;
     TreePrep p;
     p.rank = levels + UPD_POS_BITS <= 32 ? block_rank<uint32_t>(my_idx, cnt, reinterpret_cast<uint32_t *>(s_keys), s_part, bd)
                                          : block_rank<uint64_t>(my_idx, cnt, reinterpret_cast<uint64_t *>(s_keys), s_part, bd);
@@ -285,7 +300,7 @@ __device__ __forceinline__ void tree_write_levels(const prism_replay_desc &rp, i
                                                   int levels, char *lds, const SibRegs<NL> &sr) {
     const int tid = threadIdx.x;
     const bool active = tid < cnt;
-    int4 *s_rec = reinterpret_cast<int4 *>(lds + UPD_MAX * 12);         // [2][UPD_MAX]
+    int4 *s_rec = reinterpret_cast<int4 *>(lds + TW_REC.off);           // [2][UPD_MAX]
     const int rank = p.rank;
     int lo = p.lo, hi = p.hi;
     float cs = p.val, cm = p.val;
@@ -349,7 +364,7 @@ __device__ __forceinline__ void tree_dense_fetch(const prism_replay_desc &rp, ch
     if (tid < 128) {
         const float2 *src = tree_nodes(rp) + 256 + 2 * tid;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(lds + (tid >> 6) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(lds + TW_DENSE.off + (tid >> 6) * 1024), 16, 0, 0);
     }
 }
 // `walk_levels`: levels the walk covered; its last records lie in s_rec[(walk_levels & 1)].  `lds` as for the writer
@@ -357,8 +372,8 @@ __device__ __forceinline__ void tree_dense_fetch(const prism_replay_desc &rp, ch
 __device__ __forceinline__ void tree_dense_finish(const prism_replay_desc &rp, int32_t leaf, int rank, int cnt, int walk_levels,
                                                   char *lds) {
     const int tid = threadIdx.x;
-    float2 *s_dense = reinterpret_cast<float2 *>(lds);                  // [256] old values, parked by the caller
-    const int4 *s_rec = reinterpret_cast<const int4 *>(lds + UPD_MAX * 12) + (walk_levels & 1) * UPD_MAX;
+    float2 *s_dense = reinterpret_cast<float2 *>(lds + TW_DENSE.off);   // [256] old values, parked by the caller
+    const int4 *s_rec = reinterpret_cast<const int4 *>(lds + TW_REC.off) + (walk_levels & 1) * UPD_MAX;
     // the dense level's old values are in LDS (each fetching wave waits for its own LDS-DMA, then all meet) BEFORE any
     // touched node is written over its old value
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -440,12 +455,15 @@ inline bool tree_dense_ok(int64_t tree_capacity, int n, int threads) {
 // {value, lo | hi << 16, leaf, rank} per element there; per_update_finish completes the job (in a
 // later kernel, so that the two halves hide behind different neighbours).
 constexpr int PER_UPDATE_LDS_BYTES = TREE_WRITE_LDS_BYTES + 128;
+constexpr LdsRegion PU_RED{TREE_WRITE_LDS_BYTES, 128, LDS_ALWAYS};          // float [<= 32] per-wave maxima, live across all passes
+constexpr LdsRegion PU_REGIONS[] = {TW_SORTED, TW_VAL, TW_PART, TW_KEYS, TW_REC, TW_DENSE, PU_RED};
+static_assert(lds_layout_ok(PU_REGIONS, PER_UPDATE_LDS_BYTES), "priority update: LDS regions overlap");
 template <bool PREPARE_ONLY = false, bool DENSE = false>
 __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
                                  char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0,
                                  int4 *__restrict__ plan_out = nullptr, int live_threads = 0) {
-    float *s_red = reinterpret_cast<float *>(lds + TREE_WRITE_LDS_BYTES);
+    float *s_red = reinterpret_cast<float *>(lds + PU_RED.off);
     const int tid = threadIdx.x;
     // `live_threads` (a multiple of 64, >= n rounded up): the caller has already retired the waves above it -- a
     // workgroup that hosts this role with more waves than the batch needs pays for every one of them at each of the

@@ -400,39 +400,67 @@ __device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int 
     }
 }
 
-// Grid-wide barrier for a launch whose workgroups are ALL resident at once (the host checks the occupancy before it
-// picks a kernel that calls this), in two halves so that the caller can put loads between them.  *bar counts arrivals
-// over ALL launches and is never reset (64-bit: never wraps): a workgroup that drew ticket `old` belongs to launch
-// old / n, which is through when the count reaches (old / n + 1) * n -- no second atomic, no reset, no generation word.
+// Grid-wide barrier for a launch whose workgroups are ALL resident at once (the host checks the occupancy of the very
+// instantiation it launches, per device, before it picks a kernel that calls this), in two halves so that the caller can
+// put loads between them.  *bar counts arrivals over ALL launches and is never reset (64-bit: never wraps).  Every launch
+// adds exactly GRID_EPOCH to it WHATEVER ITS SHAPE: workgroup 0 weighs GRID_EPOCH - (n - 1), every other workgroup 1 -- so
+// a workgroup that drew `old` belongs to launch old >> 20, which is through when the count reaches the next multiple of
+// GRID_EPOCH: no second atomic, no reset, no generation word, and launches of different shapes (writeback riding along or
+// not, another batch size) may share one workspace without desynchronising the phase.
 //   arrive: every wave drains its own stores, the workgroup meets, one lane writes the L2 back (release) and draws
 //           its ticket (the atomic is only ISSUED here);
-//   wait:   unless it was the last to arrive, that lane polls the counter past the L2 (agent scope).
+//   wait:   unless it was the last to arrive, that lane polls the counter past the L2 (agent scope) -- for at most
+//           GRID_WAIT_TICKS of the 100 MHz real-time counter: a grid that is NOT resident at once after all (another
+//           process took part of the device) must not spin for ever.  A workgroup that gives up sets bit 0 of *status
+//           (sticky; HipAgent.check_status raises on it) and skips its update.
 // There is NO acquire: what a workgroup reads of the others' data behind the barrier it must read with agent-scope
 // loads (they do not stop at this XCD's L2) -- one cache invalidation less on everybody's path.
-__device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long long *bar) {
+constexpr unsigned long long GRID_EPOCH = 1ull << 20;
+constexpr unsigned long long GRID_WAIT_TICKS = 10000000ull;       // 100 ms; a healthy barrier takes about 2 us
+constexpr unsigned int GRID_STATUS_TIMEOUT = 1u;
+__device__ __forceinline__ unsigned long long grid_barrier_weight(unsigned int n) {
+    return blockIdx.x == 0 ? GRID_EPOCH - (unsigned long long)(n - 1) : 1ull;
+}
+__device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long long *bar, unsigned int n) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned long long old = 0;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        old = atomicAdd(bar, 1ull);
+        old = atomicAdd(bar, grid_barrier_weight(n));
     }
     return old;
 }
-__device__ __forceinline__ void grid_barrier_wait(unsigned long long *bar, unsigned long long old, unsigned int n) {
+// returns false (in every thread) when the wait was abandoned
+__device__ __forceinline__ bool grid_barrier_wait(unsigned long long *bar, unsigned long long old, unsigned int n,
+                                                  unsigned int *status) {
+    __shared__ int s_ok;
     if (threadIdx.x == 0) {
-        const unsigned long long target = (old / n + 1ull) * n;
-        if (old + 1ull < target)
-            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        const unsigned long long target = ((old >> 20) + 1ull) << 20;
+        int ok = 1;
+        if (old + grid_barrier_weight(n) < target) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > GRID_WAIT_TICKS) {
+                    ok = 0;
+                    atomicOr(status, GRID_STATUS_TIMEOUT);
+                    break;
+                }
+            }
+        }
+        s_ok = ok;
     }
     __syncthreads();
+    return s_ok != 0;
 }
 
 // the clip + Adam half of the step when it rides in the post launch (single GPU: nothing sits between the two)
 struct TailArgs {
     AdamArgs adam;
     unsigned long long *barrier;   // [1] arrivals, cumulative over all launches
+    unsigned int *status;          // [1] sticky GRID_STATUS_* bits
     uint64_t *rng;             // device RNG counters {PER draws, tau draws} advanced once per step (or NULL)
     uint64_t inc_per, inc_tau;
 };
@@ -454,8 +482,8 @@ struct TailShare {
 // them would wait for them) and the float64 bias corrections (another wave than the one that polls).  Behind it: the norm partials (and
 // the gradient where it is not owned), the 256-lane fold every launch shape uses, the update.  Bit-identical to
 // clip_adam_block.
-__device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long long *barrier, int n_role, const TailShare &sh,
-                                               int64_t step_now, unsigned long long *st) {
+__device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long long *barrier, unsigned int *status, int n_role,
+                                               const TailShare &sh, int64_t step_now, unsigned long long *st) {
     auto stamp = [&](int k) {
         if (st && threadIdx.x == 0) {
             st[(size_t)blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
@@ -468,7 +496,7 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long 
     // (the step count was requested at kernel entry; it has to have ARRIVED before this workgroup is counted in --
     // workgroup 0 overwrites it behind the barrier)
     asm volatile("" ::"s"((int)step_now), "s"((int)(step_now >> 32)));
-    const unsigned long long ticket = grid_barrier_arrive(barrier);
+    const unsigned long long ticket = grid_barrier_arrive(barrier, (unsigned)n_role);
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0;
     if (sh.have) {
         p0 = reinterpret_cast<const float4 *>(a.p)[sh.j];
@@ -481,7 +509,7 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long 
         s_c[1] = (float)(-(a.lr / bc1));
         s_c[2] = (float)sqrt(bc2);
     }
-    grid_barrier_wait(barrier, ticket, (unsigned)n_role);
+    if (!grid_barrier_wait(barrier, ticket, (unsigned)n_role, status)) return;      // (uniform: abandoned, flagged)
     stamp(25);
     // (everything another workgroup wrote is read at agent scope: the barrier has no acquire)
     auto far = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -573,7 +601,10 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     // conv-backward staging and the writeback scratch never coexist in one block: one aliased pool
     constexpr int POOL = PER_UPDATE_LDS_BYTES > (int)(CONV_LDS_FLOATS * sizeof(float)) ? PER_UPDATE_LDS_BYTES
                                                                                        : (int)(CONV_LDS_FLOATS * sizeof(float));
+    // (one role per workgroup: the roles never share the pool in time; each must fit it)
     static_assert(POOL >= (int)(SMALL_POOL_FLOATS * sizeof(float)), "small-tensor fold must fit the pool");
+    static_assert(POOL >= (int)(16 * CONV_FOLD_W * sizeof(float)) && POOL >= (int)(1024 * sizeof(float)),
+                  "conv fold staging must fit the pool");
     __shared__ __attribute__((aligned(16))) char s_pool[POOL];
     __shared__ float s_red[64];
     PRISM_STAMP(13);
@@ -797,7 +828,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             sh.j = sh.k < sh.s0 ? sh.k : sh.k + sh.cnt;
             sh.scalar_tail = rank == 0;
         }
-        tail_clip_adam(tl.adam, tl.barrier, n_role, sh, step_now, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
+        tail_clip_adam(tl.adam, tl.barrier, tl.status, n_role, sh, step_now, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
         if (!wb.enabled && tl.rng && blockIdx.x == 0 && tid == 0) {
             tl.rng[0] += tl.inc_per;
             tl.rng[1] += tl.inc_tau;

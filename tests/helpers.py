@@ -96,3 +96,31 @@ def case_act(g):
     obs = np.unpackbits(g["act/obs_bits"])[:n * 100 * C].reshape(n, 10, 10, C).astype(np.float32)
     taus = torch.from_numpy(g["act/tau"]).reshape(-1, 1) if "act/tau" in g.files else None
     return torch.from_numpy(obs), taus, {k[4:]: g[k] for k in g.files if k.startswith("act/")}
+
+
+# ---- Philox4x32-10 on the host (Salmon et al., SC'11) -- restates prism_amd/csrc/common.h::Philox so that a test can
+# re-draw what a kernel drew on the device (PER masses, quantile samples) from (seed, counter, stream key)
+def philox4x32(seed, ctr, stream):
+    """ctr: uint64 array of counters; returns uint32 array [n, 4]."""
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    c0, c1 = ctr & m32, ctr >> np.uint64(32)
+    c2 = np.full_like(ctr, np.uint64(stream) & m32)
+    c3 = np.full_like(ctr, np.uint64(stream) >> np.uint64(32))
+    a, b = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        h0, l0, h1, l1 = p0 >> np.uint64(32), p0 & m32, p1 >> np.uint64(32), p1 & m32
+        c0, c1, c2, c3 = h1 ^ c1 ^ a, l1, h0 ^ c3 ^ b, l0
+        a = (a + np.uint64(0x9E3779B9)) & m32
+        b = (b + np.uint64(0xBB67AE85)) & m32
+    return np.stack([c0, c1, c2, c3], axis=1).astype(np.uint32)
+
+
+def philox_per_mass(seed, offset, batch, p_sum):
+    """The masses step_front_kernel / per_sample_kernel draw: U(0, p_sum) in float64 (53 random bits, as numpy's
+    random_sample), narrowed to fp32 (replay_kernels.h, key "PERM")."""
+    r = philox4x32(seed, np.uint64(offset) + np.arange(batch, dtype=np.uint64), 0x5045524D)
+    a, b = (r[:, 0] >> np.uint32(5)).astype(np.float64), (r[:, 1] >> np.uint32(6)).astype(np.float64)
+    u = (a * 67108864.0 + b) / 9007199254740992.0
+    return (0.0 + (np.float64(np.float32(p_sum)) - 0.0) * u).astype(np.float32)

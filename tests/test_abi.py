@@ -84,12 +84,9 @@ def test_product_never_imports_oracle_and_has_no_cpu_path():
     assert "LOUD" in out.stdout, out.stdout + out.stderr
 
 
-def test_kernels_use_no_scratch_memory(tmp_path):
-    """A register array that lands in scratch (private segment) costs a kernel several microseconds per
-    launch on this path (it happened three times during development: indexed selects, conditionally
-    initialised arrays, kernel-argument structs passed by reference).  Compile the device code to
-    assembly and require a zero private segment for every kernel."""
-    import re
+@pytest.fixture(scope="module")
+def device_isa(tmp_path_factory):
+    """gfx950 assembly of the two translation units that hold every kernel: {source name: text}."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -97,17 +94,64 @@ def test_kernels_use_no_scratch_memory(tmp_path):
         pytest.skip("hipcc not available")
     ROOT = H.ROOT
     csrc = os.path.join(ROOT, "prism_amd", "csrc")
-    bad = []
+    tmp = tmp_path_factory.mktemp("isa")
+    out = {}
     for src in ("learner.hip", "replay.hip"):
-        out = tmp_path / (src + ".s")
+        o = tmp / (src + ".s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-S", "--cuda-device-only",
-                        "-o", str(out), os.path.join(csrc, src)], check=True, timeout=600,
+                        "-o", str(o), os.path.join(csrc, src)], check=True, timeout=900,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        text = out.read_text()
+        out[src] = o.read_text()
+    return out
+
+
+def test_kernels_use_no_scratch_memory(device_isa):
+    """A register array that lands in scratch (private segment) costs a kernel several microseconds per
+    launch on this path (it happened three times during development: indexed selects, conditionally
+    initialised arrays, kernel-argument structs passed by reference).  Require a zero private segment
+    for every kernel."""
+    bad = []
+    for src, text in device_isa.items():
         for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
             seg = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
             uses = re.search(r"scratch_(load|store)", text[text.find(m.group(1) + ":"):text.find(".amdhsa_kernel " + m.group(1))])
             if seg and int(seg.group(1)) > 0 and uses:
                 bad.append((m.group(1), int(seg.group(1))))
     assert not bad, f"kernels with scratch traffic: {bad}"
+
+
+def test_release_tickets_drain_every_wave_first(device_isa):
+    """Cross-workgroup hand-offs (the conv-partial ticket, the grid barrier of the fused tail) publish data other
+    workgroups read once the ticket says so.  The protocol: EVERY wave drains its own stores (s_waitcnt vmcnt(0)), the
+    workgroup meets (s_barrier), then one lane writes the L2 back (buffer_wbl2) and draws the ticket (a returning
+    global_atomic_add).  A barrier alone only proves the stores were issued; hipcc moves or drops the wait unless it is
+    pinned.  Check the emitted ISA: walking back from every release ticket, the last s_waitcnt before its s_barrier
+    waits for vmcnt(0), with no store in between."""
+    text = device_isa["learner.hip"]
+    lines = text.splitlines()
+    tickets = [i for i, l in enumerate(lines) if re.search(r"\bglobal_atomic_add(_x2)?\b.*\bsc0\b", l)]
+    checked, bad = 0, []
+    for i in tickets:
+        # release ticket? (a write-back between the atomic and the barrier in front of it)
+        j, wb = i - 1, False
+        while j >= 0 and "s_barrier" not in lines[j] and not re.match(r"^\S+:\s*$", lines[j].split(";")[0]) or \
+                (j >= 0 and lines[j].startswith(".LBB")):
+            wb = wb or "buffer_wbl2" in lines[j]
+            j -= 1
+        if not wb or j < 0 or "s_barrier" not in lines[j]:
+            continue          # a plain counter (e.g. "last workgroup advances the step count"): nothing is handed over
+        checked += 1
+        k, ok = j - 1, False
+        while k >= 0:                     # back from the barrier: a vmcnt(0) wait before any memory instruction or label
+            ins = lines[k].split(";")[0].strip()
+            if ins.startswith("s_waitcnt") and "vmcnt(0)" in ins:
+                ok = True
+                break
+            if re.match(r"(global|buffer|flat|scratch)_", ins) or "s_barrier" in ins or re.match(r"^\S+:$", ins):
+                break
+            k -= 1
+        if not ok:
+            bad.append((i + 1, lines[i].strip()))
+    assert checked >= 7, f"expected the conv tickets of five post-kernel forms and two grid barriers, found {checked}"
+    assert not bad, f"release tickets whose workgroup barrier is not preceded by a vmcnt(0) drain: {bad}"

@@ -159,3 +159,44 @@ def test_acting_before_the_first_update(dev):
     np.testing.assert_allclose(q.cpu().numpy(), qo.numpy(), rtol=0, atol=TOL)
     np.testing.assert_allclose(dist.cpu().numpy(), do.numpy(), rtol=0, atol=TOL)
     assert tuple(agent.forward(obs.to(dev)).shape) == (obs.shape[0],)
+
+
+@pytest.mark.parametrize("name", ["full_small", "iqn_c3", "dqn_c2", "dqn_ln"])
+def test_forward_selects_natively_also_in_pieces(dev, name):
+    """Agent.forward with MORE observations than the learner batch (the collector may pass any number): the actions come
+    from prism_ids_select / prism_greedy_select piece by piece and must have the full length and equal the selector's
+    torch code run on the same estimates (same Philox counters).  Covers deterministic IDS, greedy (eval mode) and
+    epsilon-greedy (both branches), with no ATen math in the product path for these selectors."""
+    from prism_amd.agents.action_selectors import EGreedyActionSelector, GreedyActionSelector
+    g, cfg, agent = updated_agent(name, dev)
+    C, A = int(g["C"]), int(g["A"])
+    rng = np.random.default_rng(9)
+    n = 2 * int(g["B"]) + 5
+    obs = torch.from_numpy((rng.random((n, 10, 10, C)) < 0.1).astype(np.float32)).to(dev)
+
+    def both(selector_for_torch):
+        agent._act_draws = 5000
+        act = agent.forward(obs)
+        agent._act_draws = 5000
+        q, dist = agent.act_estimates(obs)
+        want = selector_for_torch.select_action(selector_for_torch.generate_action_probs(dist, q))
+        torch.cuda.synchronize()
+        assert act.dtype == torch.int64 and tuple(act.shape) == (n,)
+        np.testing.assert_array_equal(act.cpu().numpy(), want.cpu().numpy())
+
+    both(agent.action_selector)                     # IDS (full_*) or greedy (use_e_greedy False in the fixtures)
+    agent.eval()
+    both(GreedyActionSelector())
+    agent.train()
+    # epsilon-greedy: epsilon 1 -> the host generator's actions; epsilon 0 -> the greedy kernel
+    agent.action_selector = EGreedyActionSelector(1.0, 1.0, 0, seed=7)
+    twin = np.random.RandomState(7)
+    twin.uniform(0, 1)
+    np.testing.assert_array_equal(agent.forward(obs).cpu().numpy(), twin.randint(A, size=(n,)))
+    agent.action_selector = EGreedyActionSelector(0.0, 0.0, 0, seed=7)
+    agent._act_draws = 5000
+    act = agent.forward(obs)
+    agent._act_draws = 5000
+    q, dist = agent.act_estimates(obs)
+    g_sel = GreedyActionSelector()
+    np.testing.assert_array_equal(act.cpu().numpy(), g_sel.select_action(g_sel.generate_action_probs(dist, q)).cpu().numpy())

@@ -1,0 +1,166 @@
+"""GPU: the path bench.py times -- Learner.step() fused, replayed from the hipGraph -- held to the oracle AT THE SIZES THE
+BENCH USES (B = 256 / 512, replay 100 000 -> 17 tree levels, and the 1.25 M-slot shard of configs[4] -> 21 levels).
+
+At steps 1 (eager: the first full-buffer step), 10 and 100 (graph replays) of a run the test snapshots parameters, Adam
+state and both priority trees before the step, lets the device run it, then replays that ONE step on the CPU:
+  * masses are re-drawn on the host from the same Philox counters -> ReplayOracle.sample: indices and IS weights bit-exact;
+  * n-step walk + collate of those slots through the oracle: every static-batch tensor bit-exact;
+  * LearnerOracle.update on the device's minibatch and recorded quantile samples: td <= 1e-5, parameters after Adam <= 2e-6;
+  * oracle update_priority(index, |td of the device|): EVERY node of both trees bit-exact (duplicates included), and the
+    running maximum priority.
+Reference: /root/reference/prism/learner.py:95-125 (one loop body)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CHECK_STEPS = (1, 10, 100)
+
+
+def _learner(dev, base, B, cap, **over):
+    from prism_amd.config import baseline_config
+    from prism_amd.learner import Learner
+    from prism_amd.synthetic import fill_replay
+    cfg = baseline_config(base, device=dev, batch_size=B, experience_replay_capacity=cap, **over)
+    cfg.fused_step, cfg.hip_graph = True, True
+    ln = Learner()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
+    fill_replay(ln.experience_buffer, cap, seed=5)
+    return ln, cfg
+
+
+def _oracle_ring(buf, cfg):
+    """ReplayOracle over the device ring's small arrays; observation rows are filled lazily (calloc'ed, only the sampled
+    slots' pages ever become resident: the 1.25 M-slot ring would be 4 GB of host memory otherwise)."""
+    from oracle import per_ref
+    orc = per_ref.ReplayOracle(buf.capacity, buf.obs_elems, cfg.n_step_returns_length, cfg.gamma, cfg.per_alpha, 0.5)
+    orc.reward[:] = buf.reward.cpu().numpy()
+    orc.action[:] = buf.action.cpu().numpy()
+    orc.flags[:] = buf.flags.cpu().numpy()
+    orc.link[:] = buf.link.cpu().numpy()
+    orc.length = buf._size
+    assert orc.sampler.sum_tree.capacity == buf.tree_capacity
+    return orc
+
+
+def _fill_rows(orc, buf, idx):
+    """Observation rows the n-step walk of `idx` can touch: the slots themselves and <= n_step - 1 hops of links."""
+    slots, cur = [idx], idx
+    for _ in range(orc.n_step - 1):
+        nxt = orc.link[cur]
+        cur = np.where(nxt >= 0, nxt, cur)
+        slots.append(cur)
+    s = np.unique(np.concatenate(slots))
+    st = torch.from_numpy(s).to(buf.device)
+    orc.obs[s] = buf.obs[st].cpu().numpy()
+    orc.succ_obs[s] = buf.succ_obs[st].cpu().numpy()
+
+
+def _check_step(ln, cfg, orc_ring, step):
+    from oracle.learner_ref import LearnerOracle
+    from tests import helpers as H
+    buf, agent = ln.experience_buffer, ln.agent
+    B = cfg.batch_size
+    torch.cuda.synchronize()
+    # ---- snapshot before the step
+    sd0 = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+    tg0 = None if agent.target_model is None else {k: v.detach().cpu().clone() for k, v in agent.target_model.state_dict().items()}
+    opt0 = agent.optimizer.state_dict()
+    sum0, min0 = buf.sum_tree.cpu().numpy().copy(), buf.min_tree.cpu().numpy().copy()
+    max0 = float(buf.per_state[0].item())
+    per_ctr = int(agent.rng_counters[0].item()) if agent._B is not None else 0
+    draws0 = buf._draws
+    td = ln.step(timesteps_this_iteration=1).clone()
+    torch.cuda.synchronize()
+    buf.check_status()
+    if step > 2:
+        assert any(isinstance(g, tuple) for g in agent._graphs.values()), "the step did not run from a hipGraph"
+
+    # ---- sampling: same trees, same masses -> same slots and IS weights
+    smp = orc_ring.sampler
+    smp.sum_tree.values()[:] = sum0
+    smp.min_tree.values()[:] = min0
+    smp.max_priority = max0
+    p_sum = smp.sum_tree.query(0, buf._size)
+    mass = H.philox_per_mass(buf.seed, draws0 + per_ctr, B, p_sum)
+    idx_o, w_o, ps_o, pm_o = smp.sample(buf._size, mass)
+    idx = buf._index.cpu().numpy()
+    np.testing.assert_array_equal(idx, idx_o, err_msg=f"step {step}: sampled slots")
+    np.testing.assert_array_equal(buf._weight.cpu().numpy(), w_o, err_msg=f"step {step}: IS weights")
+    assert np.float32(ps_o) == np.float32(buf.per_state[1].item()) and np.float32(pm_o) == np.float32(buf.per_state[2].item())
+    # ---- n-step walk + collate
+    _fill_rows(orc_ring, buf, idx)
+    g = orc_ring.gather(idx)
+    np.testing.assert_array_equal(buf._obs.cpu().numpy().reshape(B, -1), g["obs"])
+    np.testing.assert_array_equal(buf._next_obs.cpu().numpy().reshape(B, -1), g["next_obs"])
+    np.testing.assert_array_equal(buf._reward.cpu().numpy().ravel(), g["reward"])
+    np.testing.assert_array_equal(buf._gamma.cpu().numpy().ravel(), g["gamma"])
+    np.testing.assert_array_equal(buf._nonterminal.cpu().numpy().ravel().astype(np.uint8), g["nonterminal"])
+    np.testing.assert_array_equal(buf._action.cpu().numpy().ravel(), g["action"])
+    # ---- the TD update on that minibatch
+    batch = dict(obs=torch.from_numpy(g["obs"]).view(B, 10, 10, 4), next_obs=torch.from_numpy(g["next_obs"]).view(B, 10, 10, 4),
+                 reward=torch.from_numpy(g["reward"]), nonterminal=torch.from_numpy(g["nonterminal"].astype(bool)),
+                 gamma=torch.from_numpy(g["gamma"]), action=torch.from_numpy(g["action"]))
+    taus = []
+    if cfg.use_iqn:
+        T, Tn = cfg.iqn_n_current_state_quantile_samples, cfg.iqn_n_next_state_quantile_samples
+        taus.append(agent.tau_out[0, :T * B].cpu().reshape(-1, 1))
+        if not cfg.use_target_network or cfg.use_double_q_learning:
+            taus.append(agent.tau_out[1, :Tn * B].cpu().reshape(-1, 1))
+        if cfg.use_target_network:
+            taus.append(agent.tau_out[2, :Tn * B].cpu().reshape(-1, 1))
+    orc = LearnerOracle(sd0, H.spec_from_config(cfg), tg0)
+    orc.opt.load_state_dict(opt0)
+    td_o = orc.update(batch, torch.from_numpy(w_o), taus)
+    td_d = td.cpu()
+    err = float((td_d - td_o).abs().max())
+    assert err <= 1e-5, f"step {step}: td error {err}"
+    post = agent.model.state_dict()
+    perr = max(float((post[k].cpu() - v).abs().max()) for k, v in orc.state_dict().items())
+    assert perr <= 2e-6, f"step {step}: parameter error after Adam {perr}"
+    # ---- priority writeback with the device's own |td|: every node of both trees, duplicates included
+    smp.update_priority(idx, td_d.abs().numpy())
+    np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), smp.sum_tree.values(), err_msg=f"step {step}: sum tree")
+    np.testing.assert_array_equal(buf.min_tree.cpu().numpy(), smp.min_tree.values(), err_msg=f"step {step}: min tree")
+    assert np.float32(smp.max_priority) == np.float32(buf.per_state[0].item())
+    return err, perr, B - len(np.unique(idx))
+
+
+# (configs[1], [2], [3] of BASELINE.json at full size; configs[3] again without the fused tail -- the launch form a
+#  data-parallel step uses; the 1.25 M-slot shard of configs[4]: 21 tree levels)
+CASES = {
+    "c2_dqn_per": dict(base=1, B=256, cap=100_000),
+    "c3_iqn_per": dict(base=2, B=256, cap=100_000),
+    "c4_full": dict(base=3, B=512, cap=100_000, target_update_period=40),
+    "c4_full_split_tail": dict(base=3, B=512, cap=100_000, target_update_period=40, fuse_tail=False),
+    "c3_split_tail": dict(base=2, B=256, cap=100_000, fuse_tail=False),
+    "c5_shard_1p25M": dict(base=4, B=512, cap=1_250_000, target_update_period=40),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_graph_step_matches_oracle_at_bench_sizes(name):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    kw = dict(CASES[name])
+    base, B, cap = kw.pop("base"), kw.pop("B"), kw.pop("cap")
+    ln, cfg = _learner("cuda:0", base, B, cap, **kw)
+    buf = ln.experience_buffer
+    levels = int(np.log2(buf.tree_capacity))
+    assert levels == (21 if cap > 1_000_000 else 17)
+    ring = _oracle_ring(buf, cfg)
+    worst = [0.0, 0.0, 0]
+    for step in range(1, max(CHECK_STEPS) + 1):
+        if step in CHECK_STEPS:
+            e, p, dup = _check_step(ln, cfg, ring, step)
+            worst = [max(worst[0], e), max(worst[1], p), worst[2] + dup]
+        else:
+            ln.step(timesteps_this_iteration=1)
+    torch.cuda.synchronize()
+    assert int(ln.agent.optimizer.step_t.item()) == max(CHECK_STEPS)
+    print(f"{name}: td err {worst[0]:.2e}, param err {worst[1]:.2e}, duplicate slots seen {worst[2]}")
