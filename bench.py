@@ -64,6 +64,51 @@ def kernel_flops(cfg, B, A=6):
     return fl
 
 
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def collate_python_loop_ms(rp, B, n_batches=40):
+    """The reference's collate cost class: `_timesteps_to_batch` (/root/reference/prism/experience/timestep_buffer.py:
+    79-196) is a per-sample Python loop -- for each of the B sampled timesteps one row assignment into each of the six
+    static-batch tensors (plus the n-step walk of timestep_buffer.py:198-238 while it is not cached).  Restated here over
+    the port's ring arrays (cached n-step values, the steady state): same number of Python-level tensor row stores.
+    The port itself collates with one vectorised gather, so this is reported beside it, not inside it."""
+    rng = np.random.default_rng(1)
+    obs = torch.zeros(B, 1, 10, 10, 4)
+    next_obs = torch.zeros(B, 1, 10, 10, 4)
+    rewards, gammas = torch.zeros(B, 1), torch.ones(B, 1)
+    nonterminals, actions = torch.zeros(B, 1, dtype=torch.bool), torch.zeros(B, 1, dtype=torch.long)
+    ring_obs, ring_succ = rp.obs.reshape(-1, 10, 10, 4), rp.succ_obs.reshape(-1, 10, 10, 4)
+    t_total = 0.0
+    for _ in range(n_batches):
+        idx = rng.integers(0, rp.length, B)
+        g = rp.gather(idx)                      # the cached n-step scalars of these timesteps
+        last = idx                              # (next observation: the successor row of the slot)
+        ret, gam, done, act = g["reward"], g["gamma"], 1 - g["nonterminal"], g["action"]
+        t0 = time.perf_counter()
+        for i in range(B):
+            s = int(idx[i])
+            if done[i]:
+                obs[i] = torch.from_numpy(ring_obs[s])
+                next_obs[i] = obs[i]
+            else:
+                obs[i] = torch.from_numpy(ring_obs[s])
+                next_obs[i] = torch.from_numpy(ring_succ[int(last[i])])
+            rewards[i] = float(ret[i])
+            nonterminals[i] = 1 - int(done[i])
+            gammas[i] = float(gam[i])
+            actions[i] = int(act[i])
+        t_total += time.perf_counter() - t0
+    return t_total / n_batches * 1e3
+
+
 def cpu_baseline(cfg, seconds=20.0):
     """The CPU oracle port of the same step (C sum tree + n-step gather, torch-CPU TD update)."""
     import contextlib
@@ -122,8 +167,15 @@ def cpu_baseline(cfg, seconds=20.0):
             n += 1
         rates[th] = n / (time.perf_counter() - t0)
     best = max(rates, key=rates.get)
+    torch.set_num_threads(1)
+    collate_ms = collate_python_loop_ms(rp, B)
     torch.set_num_threads(nproc)
     return {"value": round(rates[best], 3), "unit": "steps/s", "cores": nproc, "threads": best, "kind": "port",
+            "host_cpu": host_cpu_model(),
+            "collate_python_loop_ms": round(collate_ms, 3),
+            "collate_note": "per-sample Python collate loop of the reference (timestep_buffer.py:79-196), restated over the "
+                            "port's arrays and timed on its own: NOT part of `value` (the port gathers vectorised); a "
+                            "reference learner pays it on top of every update",
             "one_thread": round(rates[1], 3), "by_threads": {str(k): round(v, 3) for k, v in rates.items()},
             "sample": f"the same workload (B={B}, replay {cap}) for {per:.1f} s at each of {sweep} torch threads: C sum-tree "
                       f"sample + n-step gather + torch-CPU TD update + priority writeback; value = best, one_thread = 1 thread"}
@@ -259,13 +311,28 @@ def main():
         abytes = algorithmic_bytes(cfg, P, P_tgt, levels)
         step_s = elapsed / args.steps
         Bsz = cfg.batch_size
-        kbytes = {"step_front_kernel": Bsz * (8 * 400 + 17) + Bsz * (4 * levels + 16),
-                  "step_back_kernel": 24 * P + 4 * Bsz + 2 * Bsz * (4 + 12 * levels)}
+        wb_bytes = (4 * Bsz + 2 * Bsz * (4 + 12 * levels)) if cfg.use_per else 0
+        kbytes = {"step_front_kernel": Bsz * (8 * 400 + 17) + (Bsz * (4 * levels + 16) if cfg.use_per else 8 * Bsz),
+                  "step_back_kernel": 24 * P + wb_bytes}
         kbytes["step_tail_kernel"] = kbytes["step_back_kernel"]      # the fused tail: the same compulsory bytes
-        traffic_all = {}
+        # the gradient reduction as a launch of its own (c4/c5): what this decomposition has to move -- every gradient
+        # slab read once, the flat gradient written once (SURVEY 8d counts gradients as on-chip: 0 compulsory bytes)
+        Hq = cfg.ids_q_head_feature_dim if cfg.use_ids else cfg.dqn_n_model_feature_dim
+        n_heads = cfg.ids_n_q_heads if cfg.use_ids else (1 if cfg.use_dqn and cfg.dqn_n_model_layers == 2 else 0)
+        if cfg.use_iqn or n_heads:
+            Hi = cfg.iqn_quantile_model_feature_dim
+            ln = 2048 if cfg.use_layer_norm else 0
+            slab = (1024 * 64 + 1024 + ln + Hi * 1024) * (8 if Hi == 128 else 4) if cfg.use_iqn else 0
+            qslab = n_heads * (ln + Hq * 1024)
+            kbytes["iqn_post_kernel"] = 4 * (slab + qslab) + 4 * P
+        traffic_all, traffic_src = {}, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic_all = json.load(open(tpath)).get(f"configs{args.config}", {})
+            tj = json.load(open(tpath))
+            traffic_all = tj.get(f"configs{args.config}", {})
+            traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("_meta", {}).get(f"configs{args.config}", "r02e"),
+                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of an earlier run of this command (not measured "
+                                   "in this run): (2*FETCH + WRITE)*1024 per launch"}
         roof = None
         if kern:
             mf = [k for k in fl if kern.get(k)]
@@ -281,13 +348,34 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom),
                         "bytes_per_launch": kbytes[dom]}
-            roof.update({"us_per_launch": round(kern[dom], 3), "kernel_us": {k: round(v, 3) for k, v in kern.items()},
+            # the genuinely memory-bound launches: achieved GB/s on their algorithmic bytes and, where a counter
+            # profile exists, on the HBM-side traffic they actually caused
+            alias = {"step_tail_kernel": "iqn_post_kernel"}       # (traffic.json names the fused tail by its kernel)
+            mem = {}
+            for k in ("step_front_kernel", "step_tail_kernel", "step_back_kernel", "iqn_post_kernel"):
+                if kern.get(k) and kbytes.get(k):
+                    us = kern[k]
+                    e = {"bytes": int(kbytes[k]), "us_event_incl_boundary": round(us, 3),
+                         "GBps": round(kbytes[k] / us / 1e3, 1), "frac_of_8TBps": round(kbytes[k] / us / 1e3 / HBM_PEAK_GBS, 4)}
+                    tr = traffic_all.get(alias.get(k, k))
+                    if tr:
+                        e.update({"traffic_bytes": int(tr), "traffic_GBps": round(tr / us / 1e3, 1),
+                                  "traffic_frac_of_8TBps": round(tr / us / 1e3 / HBM_PEAK_GBS, 4)})
+                    mem[k] = e
+            roof.update({"us_per_launch": round(kern[dom], 3), "traffic_source": traffic_src, "memory_bound_kernels": mem,
+                         "kernel_us_event_incl_boundary": {k: round(v, 3) for k, v in kern.items()},
+                         "kernel_us_note": "HIP-event pairs around each launch of eager steps: each figure includes ~3 us of "
+                                           "launch boundary, so they sum to more than ms_per_step (graph replay); rocprofv3 "
+                                           "durations are in profiles/*_kernel_stats.csv",
                          "step_hbm": {"algorithmic_bytes": abytes, "achieved_GBps": round(abytes / step_s / 1e9, 2),
                                       "peak_GBps": HBM_PEAK_GBS, "frac": round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 5)},
                          "step_mfma_frac": round(sum(fl.values()) / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)})
         out = {"metric": "learner grad-steps/sec, IQN+PER batch=256, 1/2/4/8 MI355X" if args.config == 2
                else f"learner grad-steps/sec, BASELINE configs[{args.config}]",
                "value": round(args.steps * world / elapsed, 2), "unit": "steps/s", "n_gpus": world,
+               "per_replica_steps_per_s": round(args.steps / elapsed, 2),
+               "value_note": "value = grad steps of all replicas per second (per_replica_steps_per_s x n_gpus; every replica "
+                             "steps on its own batch of `batch_per_gpu`); SURVEY 8d's per-replica step rate is per_replica_steps_per_s",
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
                "repeats": repeats, "timing": "median of `repeats` blocks of `steps` steps; min/max block ms_per_step: "
                f"{min(blocks) / args.steps * 1e3:.5f}/{max(blocks) / args.steps * 1e3:.5f}",

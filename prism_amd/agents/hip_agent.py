@@ -196,7 +196,10 @@ class HipAgent:
                                          and getattr(config, "data_parallel", False)):
             self.world = torch.distributed.get_world_size(process_group)
         self._B = None
-        self.collective_in_graph = bool(getattr(config, "collective_in_graph", True))
+        # the all-reduce captured INSIDE the step graph: opt-in (config.collective_in_graph / PRISM_COLLECTIVE_IN_GRAPH=1)
+        # until a multi-GPU run of it is on record; the default is two graphs around an eagerly launched collective
+        self.collective_in_graph = bool(getattr(config, "collective_in_graph",
+                                                os.environ.get("PRISM_COLLECTIVE_IN_GRAPH", "0") == "1"))
         self.fuse_tail = bool(getattr(config, "fuse_tail", True))
         self._capture_error = None
         self.model.train()
@@ -400,17 +403,25 @@ class HipAgent:
             # once eagerly (communicator set up outside the capture): the warm step before this one did that.  Backends
             # whose all-reduce cannot be captured (gloo: host staging) raise here; the step then falls back to two
             # graphs around an eagerly launched collective, for good.
-            g = torch.cuda.CUDAGraph()
+            g, err = torch.cuda.CUDAGraph(), None
             try:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._launch_fused(buf, d)
+            except Exception as e:          # noqa: BLE001 -- any capture failure selects the split form
+                err = repr(e)
+                torch.cuda.synchronize()
+            # every rank must run the same form: agree on the outcome (MIN over ranks of "my capture worked")
+            ok = torch.tensor([0 if err else 1], device=self.device, dtype=torch.int32)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+            if int(ok.item()) == 1:
                 g.replay()
                 return (g,)
-            except Exception as e:          # noqa: BLE001 -- any capture failure selects the split form
-                self.collective_in_graph = False
-                self._capture_error = repr(e)
-                torch.cuda.synchronize()
-                # the failed capture ran nothing, but the step must still happen exactly once: fall through
+            self.collective_in_graph = False
+            self._capture_error = err or "capture failed on another rank"
+            import warnings
+            warnings.warn(f"prism_amd: the all-reduce could not be captured into the step graph ({self._capture_error}); "
+                          "running two graphs around an eager collective")
+            # nothing of the step has run yet (a capture only records): fall through
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
             self._launch_fused(buf, d, "front")
@@ -588,11 +599,13 @@ class HipAgent:
     def load(self, directory):
         path = os.path.join(directory, "agent")
         # load_state_dict copies INTO the existing parameters, i.e. into the flat buffer views
-        self.model.load_state_dict(torch.load(os.path.join(path, "model.pt"), map_location=self.device))
-        self.optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.pt"), map_location=self.device))
+        # (tensor-only files: weights_only refuses anything that would run code on load)
+        self.model.load_state_dict(torch.load(os.path.join(path, "model.pt"), map_location=self.device, weights_only=True))
+        self.optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.pt"), map_location=self.device,
+                                                  weights_only=True))
         if self.target_model is not None:
             self.target_model.load_state_dict(torch.load(os.path.join(path, "target_model.pt"),
-                                                         map_location=self.device))
+                                                         map_location=self.device, weights_only=True))
         with open(os.path.join(path, "state.pkl"), "rb") as f:
             state = ref_pickle.load(f)         # reference-written files name prism.agents.action_selectors.*
         self._graphs = {}                      # captured graphs bake the hyper-parameters restored here

@@ -13,14 +13,23 @@
 // Shape of the computation (everything transposed so that the accumulator of one product IS the operand of
 // the next; MFMA 16x16x4 fp32: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[i = 4(l>>4)+r][j = l&15]):
 //   Y^T[n][m]    = Wphi[n][:] . cos[m][:]          A = Wphi (streamed), B = cos basis (16 registers per lane)
-//   x[n][m]      = ReLU(Y^T + bphi[n]) * e[b(m)][n]   (the bias is the initial accumulator)
+//   x[n][m]      = ReLU(Y^T + bphi[n]) * e[b(m)][n]   (the bias is added ONCE, to the finished product, as a GEMM
+//                                                  epilogue does: accumulating onto it rounds at the bias's magnitude
+//                                                  sixteen times, which shows as soon as the bias is large)
 //   pre^T[h][m] += W1g[h][n] * x[n][m]             A = W1 (streamed, LayerNorm scale folded in), B = x: the D
 //                                                  registers of the first product, used as they stand
 // Wave w owns embed columns [128w, 128w + 128): eight 16-column steps, each 16 phi MFMAs + 4 * H/16 trunk
 // MFMAs, with no barrier and no LDS traffic between them.  LayerNorm(1024) is applied AFTER the GEMM from
 // the row sums the phi epilogue accumulates on the side:
 //   LN(x) . W1^T = rstd * (x . (g*W1)^T - mean * u) + v,   u = W1 g, v = W1 beta   (front kernel roles)
-// which is what removes the row-wide synchronisation between the two products.  The eight K-slices are
+// which is what removes the row-wide synchronisation between the two products.  Written like that, both the one-pass
+// variance (E[x^2] - mean^2) and the difference x . (g*W1)^T - mean * u cancel catastrophically when a row's mean is large
+// against its spread.  So every wave SHIFTS its slice of the row by a constant c close to the row's mean -- the first
+// element the wave produces of that row -- before it squares, sums and multiplies:
+//   d = x - c_w;   x . (g*W1)^T = sum_w [ d . (g*W1)_w^T + c_w u_w ],   u_w = u restricted to the wave's 128 columns
+//   pre = rstd * ( sum_w part_w + sum_w (c_w - mean) u_w ) + v
+// and the row statistics are combined from per-wave (c_w, sum d, sum d^2) as shifted moments (Chan et al.): every
+// quantity that enters a difference is of the size of the row's spread.  One subtraction per element in the stream.  The eight K-slices are
 // folded through LDS in wave order (bitwise reproducible), then LayerNorm(H) + head run with one row per
 // 32-lane half-wave.
 #pragma once
@@ -50,7 +59,7 @@ struct FwLds {
     static constexpr unsigned STREAM = 1u, ROWS = 2u, LOSS = 4u;
     static constexpr LdsRegion COST{0, 16 * CS, STREAM};                                    // [16][CS] cos basis of the tile's rows
     static constexpr LdsRegion ROWF{COST.off + COST.size, 128, LDS_ALWAYS};                 // tau, loss scalars, b2 at [96, 112)
-    static constexpr LdsRegion STAT{ROWF.off + ROWF.size, 2 * W * 16, STREAM | ROWS};       // [2][waves][16 rows]
+    static constexpr LdsRegion STAT{ROWF.off + ROWF.size, 3 * W * 16, STREAM | ROWS};       // [3][waves][16 rows]: sum d | sum d^2 | shift
     static constexpr LdsRegion PART{STAT.off + STAT.size, W * 16 * HP, STREAM | ROWS};      // [waves][16 rows][HP]
     static constexpr LdsRegion ZT{PART.off + PART.size, 16 * FW_ZS + 16, ROWS | LOSS};      // [16][FW_ZS]
     static constexpr LdsRegion W2S{ZT.off + ZT.size, 16 * H, LDS_ALWAYS};                   // [A][H] head Linear weight
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     typedef FwLds<H> LD;
     float *cost = smem + LD::COST.off;           // [16][CS] cos basis of the tile's rows
     float *rowf = smem + LD::ROWF.off;           // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
-    float *stat = smem + LD::STAT.off;           // [2][8 waves][16 rows] partial row sums / sums of squares
+    float *stat = smem + LD::STAT.off;           // [3][8 waves][16 rows] shifted row sums / sums of squares / the shift
     float *part = smem + LD::PART.off;           // [8 waves][16 rows][HP] K-slice partials
     float *zt = smem + LD::ZT.off;               // [16][FW_ZS] quantile / Q estimates of the tile
     float *w2s = smem + LD::W2S.off;             // [A][H] head Linear weight; b2 in rowf[96, 112)
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     f32x4 accT[NHT];
 #pragma unroll
     for (int i = 0; i < NHT; ++i) accT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, cshift = 0.f;
+    static_assert(!LN || FW_WAVES == UV_SLICES, "one u slice per streaming wave");
 
     // ---------------------------------------------------------------------------------------------
     // the streamed products.  PHI: IQN rows (phi product feeds the trunk product); !PHI: Q-head rows.
@@ -284,18 +294,23 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                                    : nullptr;
         auto finish_x = [&](float (&dst)[4], int nt_e, int r) __attribute__((always_inline)) {
             const float ev = e4[nt_e & 1][r];
-            const float relu = PHI ? fmaxf(pacc[r], 0.f) : 0.f;
+            const float relu = PHI ? fmaxf(pacc[r] + b4[nt_e & 1][r], 0.f) : 0.f;
             if (PHI && PH_ALL) phs[nt_e][r] = relu;
-            dst[r] = PHI ? relu * ev : ev;
+            float xv = PHI ? relu * ev : ev;
             if (LN) {
-                s1 += dst[r];
-                s2 = fmaf(dst[r], dst[r], s2);
+                // the wave's shift of row li: the first element its g = 0 lane produces (all four lanes of the row agree)
+                if (nt_e == 0 && r == 0) cshift = __shfl(xv, li, 64);
+                xv -= cshift;
+                s1 += xv;
+                s2 = fmaf(xv, xv, s2);
             }
-            if (r == 3 && nt_e + 2 < FW_NT) e4[nt_e & 1] = *reinterpret_cast<gcf4>(erow + 16 * (nt_e + 2));
+            dst[r] = xv;
+            if (r == 3 && nt_e + 2 < FW_NT) {
+                e4[nt_e & 1] = *reinterpret_cast<gcf4>(erow + 16 * (nt_e + 2));
+                if (PHI) b4[nt_e & 1] = *reinterpret_cast<gcf4>(brow + 16 * (nt_e + 2));
+            }
         };
         if (PHI) {
-            pacc = b4[0];          // bias = initial accumulator
-            b4[0] = *reinterpret_cast<gcf4>(brow + 32);
 #pragma unroll
             for (int i = 0; i < 16; ++i) pacc = mfma16(FW_SEL(wphi0[i >> 2], i & 3), FW_SEL(cosB[i >> 2], i & 3), pacc);
         }
@@ -309,10 +324,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         for (int nt = 0; nt < FW_NT; ++nt) {
             const bool more = nt + 1 < FW_NT;
 
-            if (PHI && more) {
-                pacc = b4[(nt + 1) & 1];
-                if (nt + 3 < FW_NT) b4[(nt + 1) & 1] = *reinterpret_cast<gcf4>(brow + 16 * (nt + 3));
-            }
+            if (PHI && more) pacc = f32x4{0.f, 0.f, 0.f, 0.f};
             // trunk MFMAs of this step; the phi chain of the NEXT step is threaded between them (one phi MFMA
             // behind each trunk MFMA until it is done: consecutive links of the chain are then two issue
             // slots apart, more than the 40-cycle accumulator latency)
@@ -378,8 +390,8 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     const int64_t o_b1 = kind == 1 ? a.off.h_b1 : a.off.iqn_b1, o_g2 = kind == 1 ? a.off.h_ln2_g : a.off.iqn_ln2_g;
     const int64_t o_be2 = kind == 1 ? a.off.h_ln2_b : a.off.iqn_ln2_b;
     const bool al = kind != 1;                       // head tensors are only 4-byte aligned
-    const gcf uvp = ps_uv + (kind == 1 ? (size_t)hd * 2 * H : (size_t)0);
-    f32x4 u4[KPT], vb4[KPT], g24[KPT], be24[KPT];
+    const gcf uvp = ps_uv + (kind == 1 ? (size_t)hd * UV_ROWS * H : (size_t)0);
+    f32x4 u4[KPT], vb4[KPT], g24[KPT], be24[KPT], us4[LN ? UV_SLICES : 1][KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int h0 = 128 * k + 4 * fc;
@@ -387,6 +399,8 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         if (LN) {
             u4[k] = ld4(uvp + h0, true);
             vb4[k] = ld4(uvp + H + h0, true) + bb;
+#pragma unroll
+            for (int ww = 0; ww < UV_SLICES; ++ww) us4[LN ? ww : 0][k] = ld4(uvp + (2 + ww) * H + h0, true);
             g24[k] = ld4(Ptr + o_g2 + h0, al);
             be24[k] = ld4(Ptr + o_be2 + h0, al);
         } else {
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         if (g == 0) {
             stat[w * 16 + li] = s1;
             stat[(FW_WAVES + w) * 16 + li] = s2;
+            stat[(2 * FW_WAVES + w) * 16 + li] = cshift;
         }
     }
 #pragma unroll
@@ -414,15 +429,34 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     PRISM_STAMP(3);
 
     float mean1 = 0.f, rstd1 = 1.f;
+    float cdev[LN ? UV_SLICES : 1];            // c_w - mean of this row: what multiplies the slice sums u_w below
     if (LN) {
-        float t1 = 0.f, t2 = 0.f;
+        // shifted moments of the eight K slices (128 elements each): mean_w = c_w + s1_w / 128, M2_w = s2_w - s1_w^2 / 128;
+        // whole row: mean = avg(mean_w), M2 = sum M2_w + 128 sum (mean_w - mean)^2
+        constexpr float NW = (float)(E_DIM / UV_SLICES);
+        float cw[UV_SLICES], a1[UV_SLICES], a2[UV_SLICES], cbar = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < FW_WAVES; ++ww) {
-            t1 += stat[ww * 16 + fm];
-            t2 += stat[(FW_WAVES + ww) * 16 + fm];
+        for (int ww = 0; ww < UV_SLICES; ++ww) {
+            a1[ww] = stat[ww * 16 + fm];
+            a2[ww] = stat[(FW_WAVES + ww) * 16 + fm];
+            cw[ww] = stat[(2 * FW_WAVES + ww) * 16 + fm];
         }
-        mean1 = t1 * (1.0f / E_DIM);
-        const float var = fmaxf(t2 * (1.0f / E_DIM) - mean1 * mean1, 0.f);
+#pragma unroll
+        for (int ww = 0; ww < UV_SLICES; ++ww) {
+            cbar += cw[ww];
+            t1 += a1[ww];
+        }
+        cbar *= 1.0f / UV_SLICES;
+        const float dmean = t1 * (1.0f / E_DIM);          // mean - cbar
+        mean1 = cbar + dmean;
+        float m2 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < UV_SLICES; ++ww) {
+            const float dw = (cw[ww] - cbar) + (a1[ww] * (1.0f / NW) - dmean);      // mean_w - mean
+            m2 += (a2[ww] - a1[ww] * a1[ww] * (1.0f / NW)) + NW * (dw * dw);
+            cdev[LN ? ww : 0] = (cw[ww] - cbar) - dmean;
+        }
+        const float var = fmaxf(m2 * (1.0f / E_DIM), 0.f);
         rstd1 = 1.0f / sqrtf(var + LN_EPS);
         if (frow.save >= 0 && fc == 0) {
             (kind == 1 ? a.ws.q_mu1 : a.ws.mu1)[frow.save] = mean1;
@@ -439,10 +473,19 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             const float4 p = *reinterpret_cast<const float4 *>(&part[(ww * 16 + fm) * HP + h0]);
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
-        const float sv[4] = {s.x, s.y, s.z, s.w};
+        float sv[4] = {s.x, s.y, s.z, s.w};
+        if (LN) {
+            // the shifts come back: sum_w (c_w - mean) u_w[h]   (slices in order)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            pre[4 * k + c] = LN ? rstd1 * (sv[c] - mean1 * u4[k][c]) + vb4[k][c] : sv[c] + vb4[k][c];
+            for (int c = 0; c < 4; ++c) {
+                float t = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < UV_SLICES; ++ww) t = fmaf(cdev[LN ? ww : 0], us4[LN ? ww : 0][k][c], t);
+                sv[c] += t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pre[4 * k + c] = LN ? rstd1 * sv[c] + vb4[k][c] : sv[c] + vb4[k][c];
     }
     // ---- ReLU -> [LayerNorm(H)] -> head --------------------------------------------------------------
     float rstd2 = 1.f;

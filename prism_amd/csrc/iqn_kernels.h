@@ -53,7 +53,7 @@ struct IqnPass {
 
 struct IqnWs {           // workspace pointers (device)
     float *e_cur, *e_next;
-    float *uv;           // [2 sets][2][Hi]: u = W1 g1, v = W1 beta1 of the online / target IQN trunk
+    float *uv;           // [2 sets][UV_ROWS][Hi]: u = W1 g1 | v = W1 beta1 | u of each 128-column K slice, online / target IQN trunk
     float *wpk[2];       // [online, target] stream-packed {phi_w, w1 * ln1_g}
     float *cosb, *mu1, *rstd1, *pre1, *xhat2, *rstd2;
     float *phis;         // ReLU(phi) of the current-state rows for the backward: [row / 16][column / 16][16 rows][16 columns]
@@ -64,7 +64,7 @@ struct IqnWs {           // workspace pointers (device)
     float *q_mu1, *q_rstd1, *q_pre1, *q_xhat2, *q_rstd2;
     float *zq_cur, *zq_on, *zq_tg;
     float *q_dq, *q_c1, *q_c2, *q_dpre1, *q_lossw;
-    float *q_uv;         // [2 sets][heads][2][Hq]
+    float *q_uv;         // [2 sets][heads][UV_ROWS][Hq]
     float *q_kappa;      // [heads][Q_NORM_PARTS] partial ||theta_h||^2
     float *q_wpk[2];     // [online, target] packed W1 * ln1_g of every head
     float *de_q;         // [heads][B][E] embedding gradient of each Q head
@@ -80,6 +80,10 @@ struct IqnWs {           // workspace pointers (device)
 };
 
 constexpr int NORM_SLOTS = 2560;
+// rows of a u/v table: u (all columns) | v | u restricted to K slice w = embed columns [128 w, 128 w + 128), w = 0..7 -- the
+// slice a forward wave streams.  The forward shifts its LayerNorm(1024) input by a per-(wave, row) constant before the
+// trunk product (fwd_kernels.h); the slice sums put that constant's contribution back.
+constexpr int UV_SLICES = 8, UV_ROWS = 2 + UV_SLICES;
 // gradient slab of one row chunk, in flat-parameter order: phi_w | phi_b | [ln1_g | ln1_b] | w1
 __host__ __device__ inline int iqn_slab_floats(int H, int ln) { return E_DIM * K_BASIS + E_DIM + (ln ? 2 * E_DIM : 0) + H * E_DIM; }
 
@@ -161,25 +165,33 @@ __device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, 
 // embed: blocks [0,B) conv(obs) online; [B,2B) conv(next_obs) with target-or-online weights;
 //        blocks [2B, 2B + H/4) compute u,v.
 // ------------------------------------------------------------------------------------------
-// u[h] = sum_n W1[h][n] g1[n],  v[h] = sum_n W1[h][n] beta1[n]   (one wave per h)
+// u[h] = sum_n W1[h][n] g1[n] (whole and per K slice),  v[h] = sum_n W1[h][n] beta1[n]   (one wave per h)
 __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int set, int h, int lane) {
     const float *P = set ? a.target_params : a.params;
     const float *W1 = P + a.off.iqn_w1 + (int64_t)h * E_DIM;
     const float *g1 = P + a.off.iqn_ln1_g, *b1 = P + a.off.iqn_ln1_b;
-    float su = 0.f, sv = 0.f;
+    float su[4], sv = 0.f;
 #pragma unroll
-    for (int n = lane * 4; n < E_DIM; n += 256) {
+    for (int i = 0; i < 4; ++i) {                 // columns 4 lane + 256 i: K slice (lane >> 5) + 2 i
+        const int n = lane * 4 + 256 * i;
         const float4 w = *reinterpret_cast<const float4 *>(W1 + n);
         const float4 g = *reinterpret_cast<const float4 *>(g1 + n);
         const float4 bb = *reinterpret_cast<const float4 *>(b1 + n);
-        su += w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
+        su[i] = w.x * g.x + w.y * g.y + w.z * g.z + w.w * g.w;
         sv += w.x * bb.x + w.y * bb.y + w.z * bb.z + w.w * bb.w;
     }
-    su = wave_sum(su);
+    float *uv = a.ws.uv + (size_t)set * UV_ROWS * a.Hi;
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < UV_SLICES; ++s) {
+        const float t = wave_sum(((lane >> 5) == (s & 1)) ? su[s >> 1] : 0.f);
+        if (lane == 0) uv[(2 + s) * a.Hi + h] = t;
+        tot += t;                                 // (slices in order: what the forward's fold adds up as well)
+    }
     sv = wave_sum(sv);
     if (lane == 0) {
-        a.ws.uv[(set * 2 + 0) * a.Hi + h] = su;
-        a.ws.uv[(set * 2 + 1) * a.Hi + h] = sv;
+        uv[h] = tot;
+        uv[a.Hi + h] = sv;
     }
 }
 
@@ -192,12 +204,12 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
                                                 float *__restrict__ dst, int tid, int nthreads) {
     // thread = output position (y, x) x a group of four output channels c0, c0 + 4, c0 + 8, c0 + 12:
     // the 3x3 input patch of a channel is read once and feeds all four (their weight reads are
-    // wave-uniform broadcasts).  Per output the fmaf chain runs (ci, dy, dx)-major from the bias,
-    // exactly as in the one-output-at-a-time form.
+    // wave-uniform broadcasts).  Per output the fmaf chain runs (ci, dy, dx)-major from zero and the bias is added to the
+    // finished sum (accumulating ONTO a large bias rounds at the bias's magnitude 9 C times: tests/test_gpu_ln_stress.py).
     const int c0 = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
     float acc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = s_b[c0 + 4 * k];
+    for (int k = 0; k < 4; ++k) acc[k] = 0.f;
     for (int ci = 0; ci < C; ++ci) {
         float p[9];
 #pragma unroll
@@ -212,7 +224,7 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(fmaxf(acc[k], 0.f), &dst[(c0 + 4 * k) * 64 + (tid & 63)]);
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(fmaxf(acc[k] + s_b[c0 + 4 * k], 0.f), &dst[(c0 + 4 * k) * 64 + (tid & 63)]);
     (void)nthreads;     // (256 threads: E_DIM / 4 positions-by-group)
 }
 
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
             load_rows_b(Sn, ti + 1);
         }
         // ---- dX columns (and, width 256, the phi columns): independent MFMA chains interleaved -------------------
-        f32x4 aphi = {bphi, bphi, bphi, bphi}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 aphi = {0.f, 0.f, 0.f, 0.f}, adx = {0.f, 0.f, 0.f, 0.f}, adx2 = {0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
         if (ti < 4) PRISM_LOOP_STAMP(16 + 4 * ti);
 #pragma unroll
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
         float xv = 0.f, dpp = 0.f;
         const float ev = S.ev;
         auto elementwise = [&](int r) __attribute__((always_inline)) {
-            const float phi = PHI_SAVED ? S.ph[r] : fmaxf(aphi[r], 0.f);      // saved by the forward / recomputed (bias in the accumulator)
+            const float phi = PHI_SAVED ? S.ph[r] : fmaxf(aphi[r] + bphi, 0.f);   // saved by the forward / recomputed (bias added last, as there)
             const float h0 = phi * ev;
             const float xhat = LN ? (h0 - S.mu[r]) * S.rs[r] : h0;
             xv = LN ? xhat * g1 + be1 : h0;                 // trunk input (B operand of dW1)

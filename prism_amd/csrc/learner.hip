@@ -126,7 +126,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.ticket = (unsigned int *)c.f(8);     // first 32 bytes: the self-resetting tickets (zeroed once by the caller)
     w.e_cur = c.f((size_t)B * E_DIM);
     w.e_next = c.f((size_t)B * E_DIM);
-    w.uv = c.f(4 * Hi);
+    w.uv = c.f(2 * UV_ROWS * Hi);
     w.wpk[0] = c.f(iqn_pack_floats((int)Hi));
     w.wpk[1] = c.f(iqn_pack_floats((int)Hi));
     w.cosb = c.f(R * K_BASIS);
@@ -174,7 +174,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_c2 = c.f(RQ);
         w.q_dpre1 = c.f(RQ * Hq);
         w.q_lossw = c.f(B);
-        w.q_uv = c.f(2 * Hd * 2 * Hq);
+        w.q_uv = c.f(2 * Hd * UV_ROWS * Hq);
         w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
         w.q_wpk[0] = c.f(Hd * Hq * E_DIM);
         w.q_wpk[1] = c.f(d->has_target ? Hd * Hq * E_DIM : 0);
@@ -310,7 +310,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.grads = ld->grads;
     // passes; the tau draws are tied to stream_id in the reference's draw order (iqn_model.py:104,112-126)
     int np = 0;
-    const float *uv0 = a.ws.uv, *uv1 = a.ws.uv + 2 * a.Hi;
+    const float *uv0 = a.ws.uv, *uv1 = a.ws.uv + UV_ROWS * a.Hi;
     if (d.use_iqn) {
         a.local_loss = local_loss(d);
         if (a.local_loss) {
@@ -363,7 +363,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     if (d.n_heads > 0 && d.head_layers == 2) {
         // Q-head tiles: (B/16) x heads per pass; same online/target selection (q_ensemble.py:62-68)
         const int nt = (B / 16) * d.n_heads;
-        const float *quv0 = a.ws.q_uv, *quv1 = a.ws.q_uv + (size_t)d.n_heads * 2 * a.Hq;
+        const float *quv0 = a.ws.q_uv, *quv1 = a.ws.q_uv + (size_t)d.n_heads * UV_ROWS * a.Hq;
         auto q_pass = [&](const float *params, int set, const float *e, float *z, int save, int sid) {
             IqnPass p;
             memset(&p, 0, sizeof(p));

@@ -33,22 +33,30 @@ __device__ __forceinline__ void pack_head_w1_block(const float *__restrict__ P, 
 }
 __host__ __device__ inline int q_pack_blocks_per_head(int H) { return H * E_DIM / 4 / 256; }
 
-// u_h[hh] = sum_n W1_h[hh][n] g1_h[n],  v_h[hh] = sum_n W1_h[hh][n] beta1_h[n]   (one wave per (set, head, hh))
+// u_h[hh] = sum_n W1_h[hh][n] g1_h[n] (whole and per K slice, iqn_kernels.h UV_ROWS),  v_h[hh] = sum_n W1_h[hh][n] beta1_h[n]
+// (one wave per (set, head, hh))
 __device__ __forceinline__ void q_uv_block(const IqnArgs &a, int set, int hd, int hh, int lane) {
     const float *Ph = (set ? a.target_params : a.params) + a.off.head_base + (int64_t)hd * a.off.head_stride;
     const float *W1 = Ph + a.off.h_w1 + (int64_t)hh * E_DIM, *g1 = Ph + a.off.h_ln1_g, *b1 = Ph + a.off.h_ln1_b;
-    float su = 0.f, sv = 0.f;
+    float su[UV_SLICES], sv = 0.f;
 #pragma unroll
-    for (int n = lane; n < E_DIM; n += 64) {
-        const float wv = W1[n];
-        su += wv * g1[n];
-        sv += wv * b1[n];
+    for (int s = 0; s < UV_SLICES; ++s) {         // columns lane + 64 k, k = 2 s, 2 s + 1: K slice s
+        const int n0 = lane + 128 * s, n1 = n0 + 64;
+        const float w0 = W1[n0], w1 = W1[n1];
+        su[s] = w0 * g1[n0] + w1 * g1[n1];
+        sv += w0 * b1[n0] + w1 * b1[n1];
     }
-    su = wave_sum(su);
+    float *uv = a.ws.q_uv + ((size_t)set * a.n_heads + hd) * UV_ROWS * a.Hq;
+    float tot = 0.f;
+#pragma unroll
+    for (int s = 0; s < UV_SLICES; ++s) {
+        const float t = wave_sum(su[s]);
+        if (lane == 0) uv[(2 + s) * a.Hq + hh] = t;
+        tot += t;
+    }
     sv = wave_sum(sv);
     if (lane == 0) {
-        float *uv = a.ws.q_uv + ((size_t)set * a.n_heads + hd) * 2 * a.Hq;
-        uv[hh] = su;
+        uv[hh] = tot;
         uv[a.Hq + hh] = sv;
     }
 }
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
             const int64_t r = (int64_t)hd * B + b;
             const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
             const float *W2 = Ph + a.off.h_w2 + (int64_t)act * H;
-            const float *uv = a.ws.q_uv + (size_t)hd * 2 * H;        // (online set)
+            const float *uv = a.ws.q_uv + (size_t)hd * UV_ROWS * H;  // (online set)
             const float dq = s_dq[hd];
             float da[KH], ga[KH], ua[KH], va[KH], m1 = 0.f, m2 = 0.f;
 #pragma unroll

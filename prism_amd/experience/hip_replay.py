@@ -393,11 +393,16 @@ class HipReplayBuffer:
         ``hip_sampler.pt`` (a reference-written directory) every slot starts at the default priority."""
         from prism_amd.experience import ref_format
         d = os.path.join(path, "experience_buffer")
+        from prism_amd.util import ref_pickle
         with open(os.path.join(d, "timesteps.pkl"), "rb") as f:
-            flat = pickle.load(f)
+            flat = ref_pickle.load_plain(f)        # a flat list of numbers and booleans: no class may be named
         r = ref_format.ring_from_timesteps(flat)
         n, n_all = int(r["n_kept"]), min(int(r["obs"].shape[0]), self.capacity)
-        st = torch.load(os.path.join(d, "hip_sampler.pt")) if os.path.exists(os.path.join(d, "hip_sampler.pt")) else None
+        if n > self.capacity:
+            raise ValueError(f"the file holds {n} complete timesteps, this buffer only {self.capacity} "
+                             "(experience_replay_capacity): load it into a buffer at least as large")
+        sp = os.path.join(d, "hip_sampler.pt")
+        st = torch.load(sp, weights_only=True) if os.path.exists(sp) else None
         leaves = None
         if st is not None and "leaves" in st and int(st["size"]) == n:
             leaves = st["leaves"]

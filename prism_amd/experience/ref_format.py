@@ -24,11 +24,13 @@ FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 def serialize_ring(obs, succ_obs, reward, action, flags, link, back, slot_id, obs_shape):
     """Arrays of the first n ring slots -> the reference's flat list.
 
-    Ids: the stored ``Timestep.id`` of a slot (``slot_id``; its slot number when unknown).  A slot whose successor
+    Ids: the stored ``Timestep.id`` of a slot (``slot_id``; slots filled in bulk have none and get numbers above every
+    real id, so they cannot collide with one).  A slot whose successor
     exists but is not stored (the collector had not finished it) is written the way the reference's ``save`` does it
     (timestep_buffer.py:276-291): truncated, its successor observation kept in an artificially numbered node."""
     n = int(obs.shape[0])
-    ids = [int(slot_id[i]) if slot_id[i] >= 0 else i for i in range(n)]
+    base = max([int(v) for v in slot_id[:n] if v >= 0] + [-1]) + 1
+    ids = [int(slot_id[i]) if slot_id[i] >= 0 else base + i for i in range(n)]
     fresh = max(ids + [0]) + 1                  # ids of the truncated-successor nodes written for stored truncations
     artificial = -1                             # timestep_buffer.py:267
     shape = [int(s) for s in obs_shape]

@@ -120,9 +120,35 @@ def _check_step(ln, cfg, orc_ring, step):
     td_d = td.cpu()
     err = float((td_d - td_o).abs().max())
     assert err <= 1e-5, f"step {step}: td error {err}"
+    # Parameters after Adam: 2e-6, plus lr / adam_eps times the ill-conditioning of the tensor's gradient.  At these sizes
+    # (655 360 ReLU units in the ten Q heads of configs[3] per step, pre-activations ~ N(0, 1)) about one unit per step
+    # sits within fp32 rounding distance of zero; two correct evaluations may put it on different sides, which moves a whole
+    # row of that layer's weight gradient by the unit's contribution (here 3e-6), and d update / d g reaches lr / eps = 1.7
+    # where |g| is small against Adam's epsilon.  The oracle measures it on itself: the same gradient in float64, and in
+    # fp32 at parameters jittered by about one ulp (three draws) -- where those agree with the plain fp32 gradient the
+    # tensor is well-conditioned and the bare 2e-6 applies (as in tests/test_gpu_learner.py).
+    spec = H.spec_from_config(cfg)
+    g32 = orc.last["grads"]
+    probe = LearnerOracle(sd0, spec, tg0)
+    g64 = probe.grads_fp64(batch, torch.from_numpy(w_o), taus)
+    kink = {k: float((g32[k].double() - g64[k]).abs().max()) for k in g32}
+    gen = torch.Generator().manual_seed(1234 + step)
+    for _ in range(3):
+        jit = {k: v * (1.0 + 1.2e-7 * torch.randn(v.shape, generator=gen)) for k, v in sd0.items()}
+        pj = LearnerOracle(jit, spec, tg0)
+        pj.update(batch, torch.from_numpy(w_o), taus, apply=False)
+        for k in g32:
+            kink[k] = max(kink[k], float((pj.last["grads"][k] - g32[k]).abs().max()))
     post = agent.model.state_dict()
-    perr = max(float((post[k].cpu() - v).abs().max()) for k, v in orc.state_dict().items())
-    assert perr <= 2e-6, f"step {step}: parameter error after Adam {perr}"
+    perr, needed = 0.0, []
+    for k, v in orc.state_dict().items():
+        d = float((post[k].cpu() - v).abs().max())
+        tol = 2e-6 + (cfg.learning_rate / cfg.adam_epsilon) * 2.0 * kink[k]
+        assert d <= tol, f"step {step}: parameter error after Adam {d} in {k} (tolerance {tol}, gradient ill-conditioning {kink[k]})"
+        if d > 2e-6:
+            needed.append(k)
+        perr = max(perr, d)
+    assert len(needed) <= 4, f"step {step}: {needed} needed the ill-conditioning allowance"
     # ---- priority writeback with the device's own |td|: every node of both trees, duplicates included
     smp.update_priority(idx, td_d.abs().numpy())
     np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), smp.sum_tree.values(), err_msg=f"step {step}: sum tree")
