@@ -34,6 +34,10 @@ extern "C" {
 
 #define PRISM_MAX_NSTEP 15
 
+#define PRISM_GEMM_FP32 1
+#define PRISM_GEMM_BF16X3 2
+#define PRISM_GEMM_DEFAULT PRISM_GEMM_BF16X3
+
 /* per-slot flag bits of the replay ring */
 #define PRISM_FLAG_DONE 1u      /* Timestep.done                                            */
 #define PRISM_FLAG_TRUNC 2u     /* Timestep.truncated                                       */
@@ -231,7 +235,12 @@ typedef struct prism_learner_desc {
      * is not through after 100 ms is abandoned: the workgroup sets PRISM_WS_STATUS_BARRIER_TIMEOUT in the workspace's
      * status word and skips its update instead of spinning for ever. */
     int32_t fuse_tail;
-    int32_t reserved0;
+    /* How the forward GEMMs (quantile embedding, trunk, Q-head first layers) are multiplied: PRISM_GEMM_FP32 = the exact
+     * fp32 MFMA chain; PRISM_GEMM_BF16X3 = every fp32 operand as the sum of three bf16 pieces, the six leading piece
+     * products on the bf16 matrix pipe with fp32 accumulation (what is dropped is of the size of one fp32 rounding; same rms
+     * error against float64 as the fp32 chain, profiles/r03_split_bf16_ubench.txt); 0 = library default (environment
+     * PRISM_GEMM=fp32|bf16x3 overrides the default).  Hidden widths other than 128 always take the fp32 chain. */
+    int32_t gemm_mode;
     /* outputs */
     float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */
     float *out_q_loss;        /* [B] or NULL  (Agent._static_q_loss)                          */

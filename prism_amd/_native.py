@@ -16,6 +16,7 @@ PRISM_MAX_NSTEP = 15
 FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 STATUS_NONPOSITIVE_PSUM, STATUS_NONPOSITIVE_PMIN = 1, 2
 WS_STATUS_WORD, WS_STATUS_BARRIER_TIMEOUT = 7, 1
+GEMM_MODES = {"auto": 0, "fp32": 1, "bf16x3": 2}
 
 c_i32, c_i64, c_u64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
 
@@ -63,7 +64,7 @@ class LearnerDesc(ctypes.Structure):
                 ("tau_cur", c_vp), ("tau_next_online", c_vp), ("tau_next_target", c_vp), ("tau_out", c_vp),
                 ("seed", c_u64), ("offset", c_u64), ("rng_counters", c_vp),
                 ("fused_replay", c_vp), ("fused_index", c_vp), ("fused_alpha", c_f32), ("fused_eps", c_f32),
-                ("fuse_tail", c_i32), ("reserved0", c_i32),
+                ("fuse_tail", c_i32), ("gemm_mode", c_i32),
                 ("out_dist_loss", c_vp), ("out_q_loss", c_vp), ("out_td", c_vp), ("out_scalars", c_vp),
                 ("dbg_z", c_vp), ("dbg_stamps", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
                 ("hyper", AdamHyper)]

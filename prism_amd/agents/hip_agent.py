@@ -226,6 +226,7 @@ class HipAgent:
         self.ones_w = None
         d = N.LearnerDesc()
         d.dims, d.off, d.batch = self.dims, self.off, B
+        d.gemm_mode = N.GEMM_MODES[str(getattr(self.config, "gemm_mode", "auto"))]      # "fp32" | "bf16x3" | "auto"
         d.params, d.grads = self.flat.data_ptr(), self.grads.data_ptr()
         d.target_params = self.flat_target.data_ptr() if self.flat_target is not None else None
         d.adam_m, d.adam_v = self.optimizer.exp_avg.data_ptr(), self.optimizer.exp_avg_sq.data_ptr()

@@ -126,6 +126,57 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- fp32 products on the bf16 matrix pipe ---------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16 retires 16x the flops of v_mfma_f32_16x16x4_f32 per cycle and, unlike it, leaves the SIMD's
+// vector issue free for half of its 16 cycles.  A fp32 value is the exact sum of three bf16 pieces (hi + mid + lo, 8 + 8 + 8
+// significant bits, each rounded to nearest from what the pieces before it left); of the nine piece products of a * b the six
+// of weight >= 2^-16 are kept (hh | hm mh | hl mm lh), accumulated in fp32 inside the MFMA -- what is dropped is of the size
+// of the rounding of one fp32 multiply.  Measured (tools/ubench/split_bf16.hip, profiles/r03_split_bf16_ubench.txt): K = 1024
+// dot products of trunk-shaped data come out with the SAME rms error against float64 as the exact fp32 chain (1.57e-7 at
+// |pre| ~ 1), at 2.5x its rate with pre-split operands, 2.05x when one operand is split on the fly.
+// Operand maps (16x16x32): lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15], j = 0..7,
+// as four registers of packed bf16 pairs; D as for 16x16x4: D[row 4 (l >> 4) + r][col l & 15].
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// two fp32 -> one register of two bf16, round to nearest even (v_cvt_pk_bf16_f32); `lo` lands in the low half
+__device__ __forceinline__ unsigned int pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+}
+struct Split3 {
+    u32x4 hi, mid, lo;
+};
+// eight fp32 values -> their three bf16 pieces, element j in half (j & 1) of register j >> 1
+__device__ __forceinline__ Split3 split_bf16x3(const float (&x)[8]) {
+    Split3 s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = x[2 * p], b = x[2 * p + 1];
+        const unsigned int h = pack_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const unsigned int m = pack_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        s.hi[p] = h;
+        s.mid[p] = m;
+        s.lo[p] = pack_bf16(sa, sb);
+    }
+    return s;
+}
+// acc += a * b to fp32 accuracy: the six piece products, small ones first
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 &ah, const u32x4 &am, const u32x4 &al, const Split3 &b, f32x4 acc) {
+    acc = mfma_bf16(al, b.hi, acc);
+    acc = mfma_bf16(am, b.mid, acc);
+    acc = mfma_bf16(ah, b.lo, acc);
+    acc = mfma_bf16(am, b.hi, acc);
+    acc = mfma_bf16(ah, b.mid, acc);
+    acc = mfma_bf16(ah, b.hi, acc);
+    return acc;
+}
+
 // ---- wave64 reductions on the DPP cross-lane path (no LDS round trips, unlike __shfl_xor) --------
 // quad_perm xor-1 / xor-2, row_ror 4 / 8, then row_bcast 15 / 31: the total lands in lane 63 and is
 // returned wave-uniform through readlane.  Fixed association order -> bitwise reproducible.

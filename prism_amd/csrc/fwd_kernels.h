@@ -49,6 +49,10 @@ __host__ __device__ constexpr int fw_waves(int H) { return 8; }
 __host__ __device__ constexpr int fw_threads(int H) { return 64 * fw_waves(H); }
 constexpr int FW_STEPS = E_DIM / 16;             // 16-column steps of a tile
 constexpr int FW_ZS = 17;                        // row stride of the Z tile in LDS
+#ifndef FW_SPLIT_RING
+#define FW_SPLIT_RING 4                          // trunk operand groups a wave keeps in flight (3 KB each)
+#endif
+constexpr int FW_CBS = 36;                       // row stride (dwords) of a bf16 cos plane: 32 dwords of pairs + 4 (rows li, li + 8 share banks: 2-way)
 
 // LDS of a forward tile (floats): cos tile | tau + loss scalars | row-stat partials | K-slice partials | Z tile | head
 // weight; the loss of a mixed tile reuses the (folded, dead) K-slice partials for its two per-row products.
@@ -57,7 +61,8 @@ template <int H>
 struct FwLds {
     static constexpr int W = fw_waves(H), HP = H + 4;
     static constexpr unsigned STREAM = 1u, ROWS = 2u, LOSS = 4u;
-    static constexpr LdsRegion COST{0, 16 * CS, STREAM};                                    // [16][CS] cos basis of the tile's rows
+    // [16][CS] cos basis of the tile's rows (fp32 chain) | [3 planes][16 rows][FW_CBS] packed bf16 pieces (bf16 path)
+    static constexpr LdsRegion COST{0, 3 * 16 * FW_CBS > 16 * CS ? 3 * 16 * FW_CBS : 16 * CS, STREAM};
     static constexpr LdsRegion ROWF{COST.off + COST.size, 128, LDS_ALWAYS};                 // tau, loss scalars, b2 at [96, 112)
     static constexpr LdsRegion STAT{ROWF.off + ROWF.size, 3 * W * 16, STREAM | ROWS};       // [3][waves][16 rows]: sum d | sum d^2 | shift
     static constexpr LdsRegion PART{STAT.off + STAT.size, W * 16 * HP, STREAM | ROWS};      // [waves][16 rows][HP]
@@ -93,7 +98,7 @@ struct FwRow {           // what a lane needs to know about tile row m
     int64_t save;        // row index in the per-row save arrays, -1: not saved
 };
 
-template <int H, bool LN>
+template <int H, bool LN, bool SPLIT = false>
 __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_value) {
     kernarg_prefetch<sizeof(IqnArgs)>();
     constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128, FW_WAVES = fw_waves(H), NTHREADS = fw_threads(H);
@@ -368,6 +373,180 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         }
 #undef FW_SEL
     };
+
+    // ---------------------------------------------------------------------------------------------
+    // SPLIT: the same products on the bf16 matrix pipe (common.h: three-piece operands, six piece products, fp32
+    // accumulation -- fp32 accuracy at 2.5x the matrix rate, and the vector unit is free half of every MFMA's cycles).
+    // A wave walks its 128 columns as four 32-column double steps (K = 32 per MFMA).  Weights arrive pre-split from the
+    // packing role (iqn_kernels.h pack_split_block): 36 KB per double step for an IQN tile, through two small register
+    // rings (trunk: RW operand groups in flight, phi: 2), each slot refilled right after its last use; the cos basis is
+    // split once per tile, the trunk input (8 values per lane and double step) as the phi epilogue produces it.  The K
+    // index of the trunk operands is permuted so that lane group g's eight elements ARE its accumulator registers of the
+    // two phi n-tiles.  Dependent bf16 MFMAs on one accumulator issue back to back, so no chain threading is needed; the
+    // phi groups of double step d + 1 sit between the trunk groups of d only to spread the loads.
+    // ---------------------------------------------------------------------------------------------
+    auto stream_split = [&](auto phi_tag) __attribute__((always_inline)) {
+        constexpr bool PHI = decltype(phi_tag)::value;
+        constexpr int G = (PHI ? 4 : 0) + NHT, P0 = PHI ? 4 : 0, NDS = 4, RW = FW_SPLIT_RING, NQ = NDS * NHT, NP = NDS * 4;
+        typedef const u32x4 __attribute__((address_space(1))) *gcu4;
+        typedef const f32x4 __attribute__((address_space(1))) *gcf4;
+        const gcu4 wp = reinterpret_cast<gcu4>(ps_wpk) + (kind == 1 ? (size_t)hd * (32 * NHT * 3 * 64) : (size_t)0) +
+                        (size_t)(4 * w) * G * 3 * 64 + lane;
+        auto slot = [&](int ds, int group, int plane) __attribute__((always_inline)) { return wp[((ds * G + group) * 3 + plane) * 64]; };
+        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
+        const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
+        u32x4 wph[2][3], w1r[RW][3];
+        f32x4 e4[2], b4[2];                    // [n-tile] of the double step whose epilogue comes next (refilled by it: one
+                                               // double step, 2 k cycles, ahead of their use)
+        if (PHI) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wph[p][pl] = slot(0, p, pl);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b4[t] = *reinterpret_cast<gcf4>(brow + 16 * t);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) e4[t] = *reinterpret_cast<gcf4>(erow + 16 * t);
+#pragma unroll
+        for (int q = 0; q < RW; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w1r[q][pl] = slot(0, P0 + q, pl);
+        // the head Linear of the row phase (requested first of all): parked in LDS, read after the fold
+#pragma unroll
+        for (int i = 0; i < H / 32; ++i)
+            if (tid + 512 * i < A * H) w2s[tid + 512 * i] = w2r[i];
+        if (tid < A) rowf[96 + tid] = b2r;
+
+        unsigned int *cosp = reinterpret_cast<unsigned int *>(cost);       // [3][16][FW_CBS] dwords of bf16 pairs
+        if (PHI) {
+            if (tid < 16) {
+                const FwRow r = trow;
+                const int sid = tau_sid;
+                const gcf tin = tau_src;
+                float tau;
+                if (tin) {
+                    tau = tin[min((int64_t)r.t, (int64_t)T - 1) * a.Bt + r.b];
+                } else {
+                    uint32_t rr[4];
+                    Philox ph(a.seed);
+                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
+                    tau = u32_to_unit_float(rr[0]);
+                }
+                if (a.tau_out && r.t < T) a.tau_out[(int64_t)sid * a.maxT * a.Bt + (int64_t)r.t * a.Bt + r.b] = tau;
+                rowf[tid] = tau;
+            }
+            lds_barrier();
+            {
+                // thread = (row m, basis pair k0, k0 + 1): the cos values as torch computes them (iqn_model.py:90-92), saved in
+                // fp32 for the backward launch, and their three bf16 pieces parked as the B operand of the phi product
+                static_assert(NTHREADS == 512, "one basis pair per thread");
+                const int m = tid >> 5, k0 = 2 * (tid & 31);
+                const float tm = rowf[m];
+                const float c0 = cosf((tm * (float)(k0 + 1)) * PI_F), c1 = cosf((tm * (float)(k0 + 2)) * PI_F);
+                const FwRow r = row_of(m);
+                if (r.save >= 0) {
+                    __builtin_nontemporal_store(c0, &a.ws.cosb[r.save * K_BASIS + k0]);
+                    __builtin_nontemporal_store(c1, &a.ws.cosb[r.save * K_BASIS + k0 + 1]);
+                }
+                const unsigned int h = pack_bf16(c0, c1);
+                const float ra = c0 - __uint_as_float(h << 16), rb = c1 - __uint_as_float(h & 0xffff0000u);
+                const unsigned int md = pack_bf16(ra, rb);
+                const float sa = ra - __uint_as_float(md << 16), sb = rb - __uint_as_float(md & 0xffff0000u);
+                cosp[(0 * 16 + m) * FW_CBS + (tid & 31)] = h;
+                cosp[(1 * 16 + m) * FW_CBS + (tid & 31)] = md;
+                cosp[(2 * 16 + m) * FW_CBS + (tid & 31)] = pack_bf16(sa, sb);
+            }
+            lds_barrier();
+        }
+        // B operand of the phi product, K block kb: cos[m = li][k = 32 kb + 8 g + j] -- read from LDS at every use (three
+        // 16-byte reads per six MFMAs: free beside them, and 24 registers go to the weight ring instead)
+        auto cos_operand = [&](int kb) __attribute__((always_inline)) {
+            Split3 c;
+            c.hi = *reinterpret_cast<const u32x4 *>(&cosp[(0 * 16 + li) * FW_CBS + 16 * kb + 4 * g]);
+            c.mid = *reinterpret_cast<const u32x4 *>(&cosp[(1 * 16 + li) * FW_CBS + 16 * kb + 4 * g]);
+            c.lo = *reinterpret_cast<const u32x4 *>(&cosp[(2 * 16 + li) * FW_CBS + 16 * kb + 4 * g]);
+            return c;
+        };
+        PRISM_STAMP(1);
+
+        f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        Split3 xs;
+        float *const phi_dst = (PHI && myrow.save >= 0)
+                                   ? a.ws.phis + ((myrow.save >> 4) * (int64_t)(E_DIM / 16) + 8 * w) * 256 + (myrow.save & 15) * 16 + 4 * g
+                                   : nullptr;
+        // phi group p (0 .. 4 NDS - 1): double step p >> 2, n-tile (p >> 1) & 1, K block p & 1; ring slot p & 1
+        auto phi_group = [&](int p) __attribute__((always_inline)) {
+            const int nt2 = (p >> 1) & 1, kb = p & 1;
+            pacc[nt2] = mfma_split(wph[p & 1][0], wph[p & 1][1], wph[p & 1][2], cos_operand(kb), pacc[nt2]);
+            if (p + 2 < NP) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wph[p & 1][pl] = slot((p + 2) >> 2, (p + 2) & 3, pl);
+            }
+        };
+        // the trunk input of double step ds from its two phi accumulators (or, head rows, from e), shifted, split
+        auto epilogue = [&](int ds) __attribute__((always_inline)) {
+            float xv[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 ph4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ev = e4[t][r];
+                    const float relu = PHI ? fmaxf(pacc[t][r] + b4[t][r], 0.f) : 0.f;
+                    ph4[r] = relu;
+                    float v = PHI ? relu * ev : ev;
+                    if (LN) {
+                        if (ds == 0 && t == 0 && r == 0) cshift = __shfl(v, li, 64);
+                        v -= cshift;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                    xv[4 * t + r] = v;
+                }
+                if (PHI && phi_dst) __builtin_nontemporal_store(ph4, reinterpret_cast<f32x4 *>(phi_dst + 256 * (2 * ds + t)));
+                if (ds + 1 < NDS) {
+                    e4[t] = *reinterpret_cast<gcf4>(erow + 32 * (ds + 1) + 16 * t);
+                    if (PHI) b4[t] = *reinterpret_cast<gcf4>(brow + 32 * (ds + 1) + 16 * t);
+                }
+                if (PHI) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            xs = split_bf16x3(xv);
+        };
+        if (PHI) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) phi_group(p);
+        }
+        epilogue(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ds = 0; ds < NDS; ++ds) {
+#pragma unroll
+            for (int ht = 0; ht < NHT; ++ht) {
+                const int q = ds * NHT + ht, sl = q % RW;
+                accT[ht] = mfma_split(w1r[sl][0], w1r[sl][1], w1r[sl][2], xs, accT[ht]);
+                if (q + RW < NQ) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) w1r[sl][pl] = slot((q + RW) / NHT, P0 + (q + RW) % NHT, pl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // a phi group of the next double step behind every second trunk group (NHT = 8: four of them)
+                if (PHI && ds + 1 < NDS && (ht & 1) && (ht >> 1) < 4) {
+                    phi_group(4 * (ds + 1) + (ht >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (ds + 1 < NDS) {
+                epilogue(ds + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    if constexpr (SPLIT) {
+        static_assert(H == 128 && FW_WAVES == 8, "the bf16 path is laid out for width 128, eight streaming waves");
+        if (kind == 1) stream_split(std::false_type{});
+        else stream_split(std::true_type{});
+    } else
     {
         auto run = [&](auto phi_tag) __attribute__((always_inline)) {
             if constexpr (FW_WAVES == 12) {

@@ -107,6 +107,7 @@ struct IqnArgs {
     int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
     int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
+    int split;             // forward GEMMs on the bf16 matrix pipe (three-piece operands, common.h); packed copies laid out for it
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
     unsigned long long *stamps;   // diagnostic builds only: [block][64] shader-clock stamps (dbg & 8)
     float huber_k, dist_w;
@@ -159,6 +160,59 @@ __device__ __forceinline__ void pack_weights_block(const float *__restrict__ P, 
         }
     }
     reinterpret_cast<float4 *>(pk)[p4] = v;   // (plain store: every CU of the next launch streams these)
+}
+
+// ---- the same weights pre-split for the bf16 matrix pipe (fwd_kernels.h, stream_split; common.h mfma_split) -------------
+// Wave w of a tile owns embed columns [128 w, 128 w + 128) as four 32-column double steps; per (wave, double step) the copy
+// holds G = 4 + H/16 operand groups (Q heads: H/16), each as three u32x4 planes {hi, mid, lo} of packed bf16 per lane:
+//   group nt2 * 2 + kb  (< 4): A operand of the phi product   Wphi[n = n0 + 16 nt2 + li][k = 32 kb + 8 g + j],  j = 0..7
+//   group 4 + ht            : A operand of the trunk product  (g1 * W1)[h = 16 ht + li][n = n0 + perm(g, j)]
+//     perm(g, j) = 4 g + j (j < 4), 16 + 4 g + (j - 4) (j >= 4): K index j of the lane group IS the accumulator register of
+//     the phi product that holds that column (n-tile j >> 2, row 4 g + (j & 3)) -- no lane movement between the products.
+// u32x4 index of (wave w, double step ds, group, plane): ((4 w + ds) * G + group) * 3 + plane) * 64 + lane.  6 bytes per weight.
+__host__ __device__ inline int split_groups(int H, bool phi) { return (phi ? 4 : 0) + H / 16; }
+__host__ __device__ inline int iqn_pack_split_floats(int H) { return 32 * split_groups(H, true) * 3 * 64 * 4; }      // in floats (16 B per u32x4)
+__host__ __device__ inline int q_pack_split_floats(int H) { return 32 * split_groups(H, false) * 3 * 64 * 4; }       // per head
+__host__ __device__ inline int iqn_pack_split_blocks(int H) { return 32 * split_groups(H, true) * 64 / 256; }         // one (group, lane) per thread
+__host__ __device__ inline int q_pack_split_blocks_per_head(int H) { return 32 * split_groups(H, false) * 64 / 256; }
+
+// `wbase`: W1 of the tensor (row stride E_DIM), `g1`: LayerNorm scale or NULL, `wphi`: phi weight or NULL (Q heads);
+// `al`: the tensors are 16-byte aligned (the IQN's are, a Q head's are not)
+__device__ __forceinline__ void pack_split_block(const float *__restrict__ wphi, const float *__restrict__ wbase,
+                                                 const float *__restrict__ g1, int H, bool al, float *__restrict__ pk, int blk, int tid) {
+    const int t = blk * 256 + tid, lane = t & 63, li = lane & 15, g = lane >> 4;
+    const int G = split_groups(H, wphi != nullptr), gi = t >> 6, group = gi % G, wd = gi / G, n0 = 32 * wd;
+    float x[8];
+    auto ld4f = [&](const float *p, float *dst) {
+        if (al) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        } else {
+            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2]; dst[3] = p[3];
+        }
+    };
+    const int P0 = wphi ? 4 : 0;
+    if (group < P0) {
+        const float *src = wphi + (int64_t)(n0 + 16 * (group >> 1) + li) * K_BASIS + 32 * (group & 1) + 8 * g;
+        ld4f(src, x);
+        ld4f(src + 4, x + 4);
+    } else {
+        const float *src = wbase + (int64_t)(16 * (group - P0) + li) * E_DIM + n0 + 4 * g;
+        ld4f(src, x);
+        ld4f(src + 16, x + 4);
+        if (g1) {
+            float gg[8];
+            ld4f(g1 + n0 + 4 * g, gg);
+            ld4f(g1 + n0 + 16 + 4 * g, gg + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] *= gg[j];
+        }
+    }
+    const Split3 s = split_bf16x3(x);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(pk) + (size_t)gi * 3 * 64 + lane;
+    dst[0] = s.hi;
+    dst[64] = s.mid;
+    dst[128] = s.lo;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -82,6 +82,27 @@ static int bwd_chunks(int H) { return (H == 128 && bwd_mode() == 0) ? 8 : 4; }  
 
 static bool width_ok(int h) { return h == 128 || h == 256; }
 
+// Forward GEMMs: 1 = exact fp32 chain (v_mfma_f32_16x16x4_f32), 2 = three-piece bf16 operands on v_mfma_f32_16x16x32_bf16
+// (fp32 accuracy, common.h).  prism_learner_desc.gemm_mode picks one, 0 = the library default (PRISM_GEMM=fp32|bf16x3
+// overrides it); widths other than 128 always take the fp32 chain.
+static int default_gemm_mode() {
+    static const int mode = [] {
+        const char *e = getenv("PRISM_GEMM");
+        if (e && !strcmp(e, "fp32")) return 1;
+        if (e && !strcmp(e, "bf16x3")) return 2;
+        return PRISM_GEMM_DEFAULT;
+    }();
+    return mode;
+}
+static int use_split(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    const int mode = ld->gemm_mode == PRISM_GEMM_FP32 || ld->gemm_mode == PRISM_GEMM_BF16X3 ? ld->gemm_mode : default_gemm_mode();
+    if (mode != PRISM_GEMM_BF16X3) return 0;
+    if (d.use_iqn && d.iqn_width != 128) return 0;
+    if (d.n_heads && d.head_layers == 2 && d.head_width != 128) return 0;
+    return (d.use_iqn || (d.n_heads && d.head_layers == 2)) ? 1 : 0;
+}
+
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
@@ -127,8 +148,8 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.e_cur = c.f((size_t)B * E_DIM);
     w.e_next = c.f((size_t)B * E_DIM);
     w.uv = c.f(2 * UV_ROWS * Hi);
-    w.wpk[0] = c.f(iqn_pack_floats((int)Hi));
-    w.wpk[1] = c.f(iqn_pack_floats((int)Hi));
+    w.wpk[0] = c.f(iqn_pack_split_floats((int)Hi));      // (the larger of the two layouts: fp32 stream order / bf16 pieces)
+    w.wpk[1] = c.f(iqn_pack_split_floats((int)Hi));
     w.cosb = c.f(R * K_BASIS);
     w.phis = c.f(((R + 15) / 16) * 16 * (size_t)E_DIM);
     w.mu1 = c.f(R);
@@ -176,8 +197,8 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_lossw = c.f(B);
         w.q_uv = c.f(2 * Hd * UV_ROWS * Hq);
         w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
-        w.q_wpk[0] = c.f(Hd * Hq * E_DIM);
-        w.q_wpk[1] = c.f(d->has_target ? Hd * Hq * E_DIM : 0);
+        w.q_wpk[0] = c.f(Hd * (size_t)q_pack_split_floats((int)Hq));
+        w.q_wpk[1] = c.f(d->has_target ? Hd * (size_t)q_pack_split_floats((int)Hq) : 0);
         w.de_q = c.f(Hd * (size_t)B * E_DIM);      // (one slot for the single-Linear DQN head)
         w.q_slabs = c.f(Hd * (size_t)q_slab_floats((int)Hq, ln));
     }
@@ -276,6 +297,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
+    a.split = use_split(ld);
     a.conv_in_bwd = conv_in_bwd(ld);
     a.bg = bwd_geometry(a.Hi, a.B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0);
     a.huber_k = d.huber_k;
@@ -533,6 +555,14 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
                 constexpr int HH = decltype(h)::value;
                 constexpr bool LL = decltype(l)::value;
                 const size_t lds = fw_lds_floats<HH>() * sizeof(float);
+                if constexpr (HH == 128) {
+                    if (aa.split) {
+                        herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
+                        if (herr == hipSuccess)
+                            hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
+                        return;
+                    }
+                }
                 herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
                 if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
             });
@@ -707,6 +737,14 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
             constexpr int HH = decltype(h)::value;
             constexpr bool LL = decltype(l)::value;
             const size_t lds = fw_lds_floats<HH>() * sizeof(float);
+            if constexpr (HH == 128) {
+                if (aa.split) {
+                    herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
+                    if (herr == hipSuccess)
+                        hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
+                    return;
+                }
+            }
             herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
             if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
         });

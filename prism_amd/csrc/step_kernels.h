@@ -15,17 +15,19 @@ namespace prism {
 // IQN: per weight set (online, target) u,v (H/4 blocks, LayerNorm only) and the stream-packed weights;
 // Q heads: per head and weight set W1 packing and u_h,v_h; per head ||theta_h||^2 (online).
 struct ExtraDims {
-    int use_iqn, n_heads, has_target, head_layers, Hi, Hq, ln;
+    int use_iqn, n_heads, has_target, head_layers, Hi, Hq, ln, split;
 };
 __host__ __device__ inline ExtraDims extra_dims(const IqnArgs &a) {
-    return ExtraDims{a.use_iqn, a.n_heads, a.has_target, a.head_layers, a.Hi, a.Hq, a.ln};
+    return ExtraDims{a.use_iqn, a.n_heads, a.has_target, a.head_layers, a.Hi, a.Hq, a.ln, a.split};
 }
+__host__ __device__ inline int iqn_pack_blocks_for(int H, int split) { return split ? iqn_pack_split_blocks(H) : iqn_pack_blocks(H); }
+__host__ __device__ inline int q_pack_blocks_for(int H, int split) { return split ? q_pack_split_blocks_per_head(H) : q_pack_blocks_per_head(H); }
 __host__ __device__ inline int front_extra_blocks(const ExtraDims &d) {
     const int sets = 1 + (d.has_target ? 1 : 0);
     const int heads = d.head_layers == 1 ? 0 : d.n_heads;        // single-Linear DQN head: nothing to pack or precompute
     int n = 0;
-    if (d.use_iqn) n += sets * ((d.ln ? d.Hi / 4 : 0) + iqn_pack_blocks(d.Hi));
-    n += heads * (sets * (q_pack_blocks_per_head(d.Hq) + (d.ln ? d.Hq / 4 : 0)) + Q_NORM_PARTS);
+    if (d.use_iqn) n += sets * ((d.ln ? d.Hi / 4 : 0) + iqn_pack_blocks_for(d.Hi, d.split));
+    n += heads * (sets * (q_pack_blocks_for(d.Hq, d.split) + (d.ln ? d.Hq / 4 : 0)) + Q_NORM_PARTS);
     return n;
 }
 
@@ -37,7 +39,7 @@ __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float
     const int sets = 1 + (a.has_target ? 1 : 0);
     const bool target_done = a.has_target && a.ws.ticket[2] != 0u;
     if (a.use_iqn) {
-        const int nuv = a.ln ? a.Hi / 4 : 0, npk = iqn_pack_blocks(a.Hi);
+        const int nuv = a.ln ? a.Hi / 4 : 0, npk = iqn_pack_blocks_for(a.Hi, a.split);
         for (int set = 0; set < sets; ++set) {
             if (x < nuv) {
                 if (set && target_done) return;
@@ -47,20 +49,32 @@ __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float
             x -= nuv;
             if (x < npk) {
                 if (set && target_done) return;
-                pack_weights_block(set ? a.target_params : a.params, a.off, a.Hi, a.ln, a.ws.wpk[set], x, tid);
+                const float *Pp = set ? a.target_params : a.params;
+                if (a.split)
+                    pack_split_block(Pp + a.off.phi_w, Pp + a.off.iqn_w1, a.ln ? Pp + a.off.iqn_ln1_g : nullptr, a.Hi, true,
+                                     a.ws.wpk[set], x, tid);
+                else
+                    pack_weights_block(Pp, a.off, a.Hi, a.ln, a.ws.wpk[set], x, tid);
                 return;
             }
             x -= npk;
         }
     }
-    const int nuv = a.ln ? a.Hq / 4 : 0, npk = q_pack_blocks_per_head(a.Hq);
+    const int nuv = a.ln ? a.Hq / 4 : 0, npk = q_pack_blocks_for(a.Hq, a.split);
     const int per_head = sets * (npk + nuv) + Q_NORM_PARTS;
     const int hd = x / per_head;
     x -= hd * per_head;
     for (int set = 0; set < sets; ++set) {
         if (x < npk) {
             if (set && target_done) return;
-            pack_head_w1_block(set ? a.target_params : a.params, a.off, a.Hq, a.ln, a.ws.q_wpk[set], hd, x, tid);
+            const float *Pp = set ? a.target_params : a.params;
+            if (a.split) {
+                const float *Ph = Pp + a.off.head_base + (int64_t)hd * a.off.head_stride;
+                pack_split_block(nullptr, Ph + a.off.h_w1, a.ln ? Ph + a.off.h_ln1_g : nullptr, a.Hq, false,
+                                 a.ws.q_wpk[set] + (size_t)hd * q_pack_split_floats(a.Hq), x, tid);
+            } else {
+                pack_head_w1_block(Pp, a.off, a.Hq, a.ln, a.ws.q_wpk[set], hd, x, tid);
+            }
             return;
         }
         x -= npk;

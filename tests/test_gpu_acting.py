@@ -25,9 +25,9 @@ def dev():
     return "cuda:0"
 
 
-def updated_agent(name, dev):
+def updated_agent(name, dev, **extra):
     g = H.load_case(name)
-    cfg, agent = build_hip_agent(g, dev)
+    cfg, agent = build_hip_agent(g, dev, **extra)
     for step in range(int(g["steps"])):
         batch, w, taus = H.case_batch(g, step)
         agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev), taus=[t.to(dev) for t in taus])
@@ -36,9 +36,10 @@ def updated_agent(name, dev):
     return g, cfg, agent
 
 
+@pytest.mark.parametrize("gemm_mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", IQN_CASES)
-def test_acting_matches_reference(dev, name):
-    g, cfg, agent = updated_agent(name, dev)
+def test_acting_matches_reference(dev, name, gemm_mode):
+    g, cfg, agent = updated_agent(name, dev, gemm_mode=gemm_mode)
     obs, taus, ref = H.case_act(g)
     q, dist = agent.act_estimates(obs.to(dev), taus=None if taus is None else taus.to(dev))
     torch.cuda.synchronize()

@@ -166,6 +166,9 @@ CASES = {
     "c4_full_split_tail": dict(base=3, B=512, cap=100_000, target_update_period=40, fuse_tail=False),
     "c3_split_tail": dict(base=2, B=256, cap=100_000, fuse_tail=False),
     "c5_shard_1p25M": dict(base=4, B=512, cap=1_250_000, target_update_period=40),
+    # the exact fp32 MFMA chain in the forward GEMMs (the default is the three-piece bf16 form, prism_hip.h gemm_mode)
+    "c3_iqn_per_fp32": dict(base=2, B=256, cap=100_000, gemm_mode="fp32"),
+    "c4_full_fp32": dict(base=3, B=512, cap=100_000, target_update_period=40, gemm_mode="fp32"),
 }
 
 

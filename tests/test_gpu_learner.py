@@ -51,11 +51,14 @@ IQN_CASES = ["iqn_small", "iqn_c3", "iqn_tau32", "iqn_target", "iqn_doubleq",
              "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub"]
 
 
+# Both ways of multiplying the forward GEMMs (include/prism_hip.h gemm_mode) are held to the same fixtures at the same
+# tolerances: the exact fp32 MFMA chain, and fp32 operands as three bf16 pieces on the bf16 matrix pipe.
+@pytest.mark.parametrize("gemm_mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", IQN_CASES)
-def test_iqn_update_matches_reference_and_oracle(dev, name):
+def test_iqn_update_matches_reference_and_oracle(dev, name, gemm_mode):
     from oracle.learner_ref import LearnerOracle
     g = H.load_case(name)
-    cfg, agent = build_hip_agent(g, dev)
+    cfg, agent = build_hip_agent(g, dev, gemm_mode=gemm_mode)
     # init parity by construction
     s0 = np.array([float(v.double().sum()) for v in agent.model.state_dict().values()])
     np.testing.assert_array_equal(s0, g["init_sum"])

@@ -25,14 +25,15 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("phi_bias,conv_bias", [(0.0, 0.0), (10.0, 2.0), (30.0, 5.0), (100.0, 10.0)])
+@pytest.mark.parametrize("gemm_mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", ["iqn_c3", "full_c4"])
-def test_layernorm_rows_with_large_mean(name, phi_bias, conv_bias):
+def test_layernorm_rows_with_large_mean(name, phi_bias, conv_bias, gemm_mode):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle.learner_ref import LearnerOracle, composite_losses
     dev = "cuda:0"
     g = H.load_case(name)
-    cfg, agent = build_hip_agent(g, dev)
+    cfg, agent = build_hip_agent(g, dev, gemm_mode=gemm_mode)
     with torch.no_grad():
         sd = agent.model.state_dict()            # views of the flat parameter buffer: written in place
         sd["distribution_model.phi.0.bias"] += phi_bias
@@ -57,7 +58,7 @@ def test_layernorm_rows_with_large_mean(name, phi_bias, conv_bias):
     floor = float((dl32.double() - dl64).abs().max())            # what fp32 arithmetic costs torch itself here
     err64 = float((dl.double() - dl64).abs().max())
     err32 = float((dl - dl32).abs().max())
-    print(f"{name} phi_bias {phi_bias} conv_bias {conv_bias}: |dl - fp64| {err64:.2e} (torch fp32: {floor:.2e}), |dl - fp32 oracle| {err32:.2e}")
+    print(f"{gemm_mode} {name} phi_bias {phi_bias} conv_bias {conv_bias}: |dl - fp64| {err64:.2e} (torch fp32: {floor:.2e}), |dl - fp32 oracle| {err32:.2e}")
     assert err64 <= 2.0 * floor + 3e-6, f"kernel loss error vs fp64 {err64} against torch's own fp32 error {floor}"
     if phi_bias <= 10.0:
         assert err32 <= 1e-5, f"loss error vs the fp32 oracle {err32}"
