@@ -330,6 +330,33 @@ int prism_sync_target(float *target_params, const float *params, int64_t n_param
                       prism_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Direct all-reduce (sum) of the flat gradient over peer-mapped buffers -- the data-parallel step's one exchange
+ * (the reference has no collective: prism/learner.py:95-125 is a single process).  An
+ * alternative to the RCCL all-reduce between prism_learner_fwd_bwd and prism_step_back for the 0.8 - 6 MB messages of
+ * this path on a fully connected xGMI node: two shots, every GPU pulling 1/world of the buffer from all peers at once.
+ *   bufs[s]   rank s's gradient buffer as mapped into THIS process (own buffer at [rank]); the host maps the peers
+ *             (hipIpcGetMemHandle / hipIpcOpenMemHandle, or the sharing of its tensor library)
+ *   flags[s]  rank s's flag array, PRISM_MAX_PEERS + 2 uint32 zeroed once, mapped likewise (use_flags only)
+ * prism_direct_reduce_scatter: slice `rank` of the own buffer := sum over s = 0..world-1 (in that order) of slice `rank`
+ * of bufs[s];  prism_direct_all_gather: every other slice := its owner's.  Afterwards all ranks hold bit-identical sums.
+ * Synchronisation: all ranks must have finished writing before the reduce-scatter, finished the reduce-scatter before
+ * the all-gather, and finished the all-gather before anyone overwrites its buffer.  use_flags = 0: the CALLER provides
+ * these three barriers (the only legal form when ranks share a device); use_flags = 1 (one device per rank): one-workgroup
+ * kernels signal and poll the flag arrays on the stream (phase numbers come from a counter in the flag array itself, so the
+ * calls may be captured into a hipGraph and replayed).  A wait that is not through after 2 s sets
+ * flags[rank][PRISM_MAX_PEERS] and falls through.
+ * ------------------------------------------------------------------------------------------ */
+#define PRISM_MAX_PEERS 8
+typedef struct prism_direct_desc {
+    int32_t world, rank;
+    float *bufs[PRISM_MAX_PEERS];
+    uint32_t *flags[PRISM_MAX_PEERS];
+    int64_t n;             /* floats */
+} prism_direct_desc;
+int prism_direct_reduce_scatter(const prism_direct_desc *d, int32_t use_flags, prism_stream_t stream);
+int prism_direct_all_gather(const prism_direct_desc *d, int32_t use_flags, prism_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the
  * roofline figure; off by default, adds two event records per instrumented launch).
  * Kernel ids: 0 embed, 1 fwd_tile, 2 loss, 3 bwd, 4 post, 5 front, 6 clip_adam, 7 per_sample,

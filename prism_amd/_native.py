@@ -70,6 +70,13 @@ class LearnerDesc(ctypes.Structure):
                 ("hyper", AdamHyper)]
 
 
+MAX_PEERS = 8
+
+
+class DirectDesc(ctypes.Structure):
+    _fields_ = [("world", c_i32), ("rank", c_i32), ("bufs", c_vp * MAX_PEERS), ("flags", c_vp * MAX_PEERS), ("n", c_i64)]
+
+
 _P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol declared in include/prism_hip.h
 SIGNATURES = {
@@ -99,6 +106,8 @@ SIGNATURES = {
                                         c_vp, c_vp]),
     "prism_greedy_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "prism_direct_reduce_scatter": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),
+    "prism_direct_all_gather": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),
     "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),
     "prism_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),

@@ -202,7 +202,20 @@ class HipAgent:
                                                 os.environ.get("PRISM_COLLECTIVE_IN_GRAPH", "0") == "1"))
         self.fuse_tail = bool(getattr(config, "fuse_tail", True))
         self._capture_error = None
+        # the step's one exchange: "rccl" (torch.distributed all_reduce, the default) or "direct" (two shots over peer-mapped
+        # buffers, prism_amd/dist.py DirectAllReduce)
+        self.collective = str(getattr(config, "collective", "rccl"))
+        self._direct = None
+        if self.world > 1 and self.collective == "direct":
+            self._direct = pdist.DirectAllReduce(self.grads, self.pg)
+            if not self._direct.use_flags:
+                self.collective_in_graph = False          # host-side barriers cannot be captured
         self.model.train()
+
+    def _allreduce(self):
+        if self._direct is not None:
+            return self._direct.allreduce(self.grads)
+        return pdist.allreduce_grads(self.grads, self.pg)
 
     # ------------------------------------------------------------------ descriptor
     def _prepare(self, B):
@@ -303,7 +316,7 @@ class HipAgent:
         with torch.cuda.device(self.device):
             N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), N.current_stream_handle()), "prism_learner_fwd_bwd")
             if self.world > 1:
-                pdist.allreduce_grads(self.grads, self.pg)
+                self._allreduce()
             N.check(L.prism_learner_clip_adam(ctypes.byref(d), N.current_stream_handle()), "prism_learner_clip_adam")
         self._keep = keep
         self._static_total_loss = self.scalars[0]
@@ -347,7 +360,7 @@ class HipAgent:
             N.check(L.prism_learner_fwd_bwd(ctypes.byref(d), st()), "prism_learner_fwd_bwd")
             d.embed_done = 0
         if part == "all" and self.world > 1:
-            pdist.allreduce_grads(self.grads, self.pg)
+            self._allreduce()
         if part in ("all", "back"):
             N.check(L.prism_step_back(ctypes.byref(d), rp, N.ptr(buf._index), smp._alpha, smp._eps, st()),
                     "prism_step_back")
@@ -427,7 +440,7 @@ class HipAgent:
         with torch.cuda.graph(g1):
             self._launch_fused(buf, d, "front")
         g1.replay()
-        pdist.allreduce_grads(self.grads, self.pg)
+        self._allreduce()
         with torch.cuda.graph(g2):
             self._launch_fused(buf, d, "back")
         g2.replay()
@@ -438,7 +451,7 @@ class HipAgent:
             g[0].replay()
         else:
             g[0].replay()
-            pdist.allreduce_grads(self.grads, self.pg)
+            self._allreduce()
             g[1].replay()
 
     # ------------------------------------------------------------------ acting

@@ -104,3 +104,137 @@ def test_two_ranks_on_identical_data_equal_single_replica():
     torch.cuda.synchronize()
     # (g + g) * 0.5 == g exactly; only the clip norm is summed in a different order
     np.testing.assert_allclose(p0, ln.agent.flat.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+# ---- the direct all-reduce (prism_direct_reduce_scatter / prism_direct_all_gather over peer-mapped buffers)
+def _direct_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from prism_amd import dist as pdist
+    ok = True
+    for n in (201_430, 1_544_210, 7, 4096):                 # configs[2] / configs[3] parameter counts, a tail-only and an even size
+        g = torch.Generator(device="cuda:0").manual_seed(100 + rank)
+        flat = torch.randn(n, device="cuda:0", generator=g)
+        want = flat.cpu()
+        dist.all_reduce(want)                                # the oracle: gloo over host memory
+        ar = pdist.DirectAllReduce(flat)
+        assert ar.use_flags is False                         # two ranks on ONE device: host-side barriers, no device spinning
+        scale = ar.allreduce()
+        torch.cuda.synchronize()
+        ar.check_status()
+        ok = ok and scale == 1.0 / world and torch.equal(flat.cpu(), want)      # (two addends: the sum is order-free, bit for bit)
+        # a second round on the same mapping (what a training loop does)
+        flat.copy_(torch.full((n,), float(rank + 1), device="cuda:0"))
+        ar.allreduce()
+        torch.cuda.synchronize()
+        ok = ok and bool((flat == float(sum(range(1, world + 1)))).all())
+        dist.barrier()
+        del ar
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_direct_allreduce_equals_the_collective():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240), q.get(timeout=240)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def _direct_learner_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from prism_amd import dist as pdist
+    from prism_amd.config import baseline_config
+    from prism_amd.learner import Learner
+    from prism_amd.synthetic import fill_replay
+    cfg = baseline_config(2, device="cuda:0", batch_size=32, experience_replay_capacity=2048, collective="direct")
+    ln = Learner()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6, process_group=dist.group.WORLD)
+    buf, ag = ln.experience_buffer, ln.agent
+    assert ag._direct is not None and ag.world == world
+    _, buf.seed, ag.seed = pdist.rank_seeds(cfg.seed, rank)
+    fill_replay(buf, 2048, seed=rank)
+    for step in range(5):
+        ln.step()
+        torch.cuda.synchronize()
+        assert pdist.assert_replicas_identical(ag.flat.cpu())
+    q.put((rank, ag.flat.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_learner_steps_over_the_direct_allreduce():
+    """The data-parallel step with collective = "direct": replicas bit-identical after every step, and equal to the run
+    whose gradients travel through the process group's all_reduce (two addends: same bits)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_learner_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240), q.get(timeout=240)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    (_, p0, _, _), _ = _run(same_data=False)               # the same two shards through the host all_reduce
+    np.testing.assert_array_equal(res[0][1], p0)
+
+
+def test_direct_allreduce_flag_kernels_single_rank_and_graph_replay():
+    """The device-flag form needs one device per rank, which this box does not have; what CAN run here is its one-rank
+    degenerate case (signal to / wait on the own flag array): the phase counter lives on the device and advances per
+    all-reduce, also when the calls are replayed from a captured hipGraph."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes
+    from prism_amd import _native as N
+    dev = "cuda:0"
+    flat = torch.randn(10_007, device=dev)
+    want = flat.clone()
+    flags = torch.zeros(N.MAX_PEERS + 2, dtype=torch.int32, device=dev)
+    d = N.DirectDesc()
+    d.world, d.rank, d.n = 1, 0, flat.numel()
+    d.bufs[0], d.flags[0] = flat.data_ptr(), flags.data_ptr()
+
+    def allreduce():
+        N.check(N.lib().prism_direct_reduce_scatter(ctypes.byref(d), 1, N.current_stream_handle()), "reduce_scatter")
+        N.check(N.lib().prism_direct_all_gather(ctypes.byref(d), 1, N.current_stream_handle()), "all_gather")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        allreduce()
+        allreduce()
+        s.synchronize()
+        f = flags.cpu().numpy()
+        assert f[N.MAX_PEERS + 1] == 2 and f[0] == 3 * 1 + 3 and f[N.MAX_PEERS] == 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            allreduce()
+        for _ in range(3):
+            g.replay()
+        s.synchronize()
+    f = flags.cpu().numpy()
+    assert f[N.MAX_PEERS + 1] == 5 and f[0] == 3 * 4 + 3 and f[N.MAX_PEERS] == 0
+    assert torch.equal(flat, want)
