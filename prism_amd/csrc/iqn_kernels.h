@@ -64,6 +64,8 @@ struct IqnWs {           // workspace pointers (device)
     float *q_mu1, *q_rstd1, *q_pre1, *q_xhat2, *q_rstd2;
     float *zq_cur, *zq_on, *zq_tg;
     float *q_dq, *q_c1, *q_c2, *q_dpre1, *q_lossw;
+    unsigned short *q_pp;   // [3 planes][heads * B][Hq] bf16 pieces of q_dpre1 (hi | mid | lo), written by the Q loss for qh_bwd2_kernel
+    unsigned short *q_xp;   // [3 planes][B][E] bf16 pieces of xhat = (e - mean) rstd of the current observations (LN off: e)
     float *q_uv;         // [2 sets][heads][UV_ROWS][Hq]
     float *q_kappa;      // [heads][Q_NORM_PARTS] partial ||theta_h||^2
     float *q_wpk[2];     // [online, target] packed W1 * ln1_g of every head
@@ -107,6 +109,9 @@ struct IqnArgs {
     int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
     int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
+    int q_de_slots;        // slots of ws.de_q that hold a share of the Q heads' embedding gradient (one per head, or the
+                           // two K halves of qh_bwd2_kernel)
+    int q_pieces;          // the Q loss also leaves dpre1 / xhat as bf16 pieces in ws.q_pp / ws.q_xp (experiments; 0)
     int split;             // forward GEMMs on the bf16 matrix pipe (three-piece operands, common.h); packed copies laid out for it
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
     unsigned long long *stamps;   // diagnostic builds only: [block][64] shader-clock stamps (dbg & 8)
@@ -1056,10 +1061,10 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
         float dh[16];                                    // every head's value requested before the first add
 #pragma unroll
-        for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.n_heads ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
+        for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.q_de_slots ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
 #pragma unroll
         for (int hd = 0; hd < 16; ++hd)
-            if (hd < a.n_heads) d += dh[hd];             // heads in fixed order
+            if (hd < a.q_de_slots) d += dh[hd];          // slots in fixed order
         s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();

@@ -15,6 +15,7 @@
 #include "step_kernels.h"
 #include "fwd_kernels.h"
 #include "act_kernels.h"
+#include "qbwd2_kernels.h"
 
 namespace prism {
 
@@ -194,6 +195,8 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_c1 = c.f(RQ);
         w.q_c2 = c.f(RQ);
         w.q_dpre1 = c.f(RQ * Hq);
+        w.q_pp = (unsigned short *)c.f(RQ * Hq * 3 / 2);
+        w.q_xp = (unsigned short *)c.f((size_t)B * E_DIM * 3 / 2);
         w.q_lossw = c.f(B);
         w.q_uv = c.f(2 * Hd * UV_ROWS * Hq);
         w.q_kappa = c.f(Q_MAX_HEADS * Q_NORM_PARTS);
@@ -298,6 +301,9 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
     a.split = use_split(ld);
+    // the Q heads' input-side backward as two shared-operand GEMMs on the bf16 pipe (qbwd2_kernels.h) where it applies
+    a.q_de_slots = d.n_heads;
+    if (a.split && qb2_ok(a.Hq, B, d.n_heads, d.head_layers)) a.q_de_slots = 2;
     a.conv_in_bwd = conv_in_bwd(ld);
     a.bg = bwd_geometry(a.Hi, a.B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0);
     a.huber_k = d.huber_k;
@@ -637,7 +643,22 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         }
         PRISM_CHECK_LAUNCH();
     }
-    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2) {
+    if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2 && a.split && qb2_ok(a.Hq, B, ld->dims.n_heads, ld->dims.head_layers)) {
+        ProfileScope ps_(K_Q_BWD, stream);
+        const dim3 grid(qb2_blocks(ld->dims.n_heads, B));
+        if (a.ln) {
+            herr = set_max_lds((const void *)qh_bwd2_kernel<true>, QB2_LDS_BYTES);
+            if (herr == hipSuccess) hipLaunchKernelGGL((qh_bwd2_kernel<true>), grid, dim3(256), QB2_LDS_BYTES, stream, a);
+        } else {
+            herr = set_max_lds((const void *)qh_bwd2_kernel<false>, QB2_LDS_BYTES);
+            if (herr == hipSuccess) hipLaunchKernelGGL((qh_bwd2_kernel<false>), grid, dim3(256), QB2_LDS_BYTES, stream, a);
+        }
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(qh_bwd2): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
+        PRISM_CHECK_LAUNCH();
+    } else if (ld->dims.n_heads > 0 && ld->dims.head_layers == 2) {
         ProfileScope ps_(K_Q_BWD, stream);
         dispatch_hl(a.Hq, a.ln, [&](auto h, auto l) {
             constexpr int HH = decltype(h)::value;

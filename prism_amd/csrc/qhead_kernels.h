@@ -190,6 +190,22 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         a.out_td[b] = a.use_iqn ? (a.out_dl[b] * 0.5f + ql * 0.5f) : fabsf(ql);
         if (b == 0) a.out_scalars[4] = theil;
     }
+    if (a.q_pieces) {
+        // xhat of this sample's embedding as three bf16 pieces (the shared B operand of qh_bwd2_kernel's G product); the
+        // row statistics are head 0's (every head normalises the same embedding)
+        const float mu = LN ? a.ws.q_mu1[b] : 0.f, rs = LN ? a.ws.q_rstd1[b] : 1.f;
+        const float2 ev = *reinterpret_cast<const float2 *>(a.ws.e_cur + (size_t)b * E_DIM + 2 * tid);
+        const float x0 = (ev.x - mu) * rs, x1 = (ev.y - mu) * rs;
+        const unsigned int hp = pack_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(hp << 16), r1 = x1 - __uint_as_float(hp & 0xffff0000u);
+        const unsigned int mp = pack_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(mp << 16), s1 = r1 - __uint_as_float(mp & 0xffff0000u);
+        unsigned int *xp = reinterpret_cast<unsigned int *>(a.ws.q_xp);
+        const size_t plane = (size_t)B * E_DIM / 2, o = (size_t)b * (E_DIM / 2) + tid;
+        xp[o] = hp;
+        xp[plane + o] = mp;
+        xp[2 * plane + o] = pack_bf16(s0, s1);
+    }
     // head + LayerNorm(H) backward of row (head, b)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -221,6 +237,16 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
                 const float gv = LN ? rs[i] * (da[k] - m1 - xa[i][k] * m2) : da[k];
                 ga[k] = pa[i][k] > 0.f ? gv : 0.f;
                 a.ws.q_dpre1[r * H + 64 * k + lane] = ga[k];
+                if (a.q_pieces) {                 // (a consumer of bf16 pieces of dpre1: split here, once; none at present -- qbwd2_kernels.h)
+                    const size_t plane = (size_t)Hd * B * H, o = (size_t)r * H + 64 * k + lane;
+                    const unsigned int hp = pack_bf16(ga[k], 0.f);
+                    const float r1 = ga[k] - __uint_as_float(hp << 16);
+                    const unsigned int mp = pack_bf16(r1, 0.f);
+                    const float r2 = r1 - __uint_as_float(mp << 16);
+                    a.ws.q_pp[o] = (unsigned short)hp;
+                    a.ws.q_pp[plane + o] = (unsigned short)mp;
+                    a.ws.q_pp[2 * plane + o] = (unsigned short)pack_bf16(r2, 0.f);
+                }
                 c1 += ga[k] * ua[k];
                 c2 += ga[k] * (pa[i][k] - va[k]);
             }
