@@ -1,0 +1,253 @@
+// IQN backward on the bf16 matrix pipe (width 128): dX, dWphi, dW1 with three-piece operands (common.h), the row operands
+// split ONCE per workgroup into LDS and shared by its four waves.
+//
+// Restates the backward of /root/reference/prism/agents/models/iqn_model.py:48-93 (+ ffnn_model.py:61-76) as
+// iqn_bwd_kernel (iqn_kernels.h) does -- the same products, the same element-wise LayerNorm / ReLU / Hadamard backward,
+// the same column-slice ownership of every weight gradient -- with another division of labour:
+//   iqn_bwd_kernel   workgroup = 16 columns x a row chunk; its four waves walk DIFFERENT rows, each loads the row operands
+//                    (dpre1 in two layouts, cos) itself; fp32 MFMA, whose issue excludes every vector instruction
+//   iqn_bwd3_kernel  workgroup = 64 columns x a row chunk; its four waves own 16 columns each and walk the SAME 32-row blocks:
+//                    dpre1 [32][128] and cos [32][64] are fetched once, split into bf16 planes once (256 threads share the
+//                    work) and parked in LDS; a wave takes dpre1 as the A operand of dX by row reads and as the A operand of
+//                    dW1 by transposed reads of the same image, cos as the B operand of dWphi by transposed reads; the
+//                    element-wise results (dphi, x: 8 values a lane) are split in registers and ARE the remaining operands
+//                    (K index = the block's rows in accumulator order: two transposed reads at rows 4g and 16 + 4g).
+// Used for the models with Q heads (their conv backward is a role of the post launch anyway).  For IQN-only models
+// iqn_bwd_kernel stays: its conv-backward taps ride behind its tile loop, and carrying them here (measured: taps in this
+// kernel's loop, observation rows by LDS-DMA) cost what the faster products gained -- 25.8 us against 27.1 with the tail
+// launch 1.6 us longer over sixteen gradient slabs instead of eight.
+// No cross-wave reduction: a wave owns its columns over all rows of the chunk.  Per 32 x 16 block and wave: 120 bf16 MFMAs
+// (1920 cycles, half of them open to vector issue) and ~450 vector instructions, against 160 fp32 MFMAs (5120) + ~900.
+// L2 traffic per row operand byte drops four-fold (64 columns per fetch instead of 16).
+#pragma once
+#include "iqn_kernels.h"
+#include "qbwd2_kernels.h"
+
+namespace prism {
+
+constexpr int BW3_H = 128, BW3_RB = 32;            // width; rows per block
+constexpr int BW3_RC = 16;                        // row chunks (gradient slabs)
+constexpr int BW3_PROW = 2 * 128 + 32, BW3_CROW = 2 * 64 + 32;      // LDS row strides (bytes): transposed reads conflict-free
+constexpr int BW3_P = BW3_RB * BW3_PROW, BW3_C = BW3_RB * BW3_CROW;  // one plane
+constexpr int BW3_BUF = 3 * (BW3_P + BW3_C);
+constexpr int BW3_LDS_BYTES = 2 * BW3_BUF;
+constexpr LdsRegion BW3_REGIONS[] = {{0, 3 * BW3_P, 1u}, {3 * BW3_P, 3 * BW3_C, 1u}, {BW3_BUF, 3 * BW3_P, 1u}, {BW3_BUF + 3 * BW3_P, 3 * BW3_C, 1u}};
+static_assert(lds_layout_ok(BW3_REGIONS, BW3_LDS_BYTES), "backward (bf16): LDS images overlap");
+static_assert(BW3_PROW % 16 == 0 && BW3_CROW % 16 == 0, "16-byte aligned image rows");
+
+inline bool bw3_ok(int H, int B, int T, bool phi_saved) { return H == BW3_H && phi_saved && (B * T) % (BW3_RC * BW3_RB) == 0 && ((B * T) / BW3_RC) % T == 0; }
+
+// 16x16x32 operand whose K index runs over the block's rows in ACCUMULATOR order (k = (g, j): row 4 g + j for j < 4, row
+// 16 + 4 g + (j - 4) above): two transposed reads of a [row][x] image, columns x0 .. x0 + 15
+__device__ __forceinline__ u32x4 bw3_tr_rows(const char *plane, int row_bytes, int x0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const char *a0 = plane + (4 * g + q) * row_bytes + 2 * (x0 + 4 * p);
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)a0);
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(a0 + 16 * row_bytes));
+    const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+    return u32x4{u0.x, u0.y, u1.x, u1.y};
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
+    kernarg_prefetch<sizeof(IqnArgs)>();
+    constexpr int H = BW3_H, NHT = H / 16;
+    constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    char *smem = reinterpret_cast<char *>(smem_f);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    // (the row chunk in the low bits of the index: the 16 column groups of a chunk share an XCD, i.e. one L2 holds its rows)
+    const int rc = blockIdx.x % BW3_RC, cg = blockIdx.x / BW3_RC;
+    const int n = 64 * cg + 16 * w + li, cs = 4 * cg + w;           // this lane's embed column; the wave's 16-column slice
+    const int T = a.T, R = a.B * T, rpc = R / BW3_RC, row0 = rc * rpc, nblk = rpc / BW3_RB;
+    typedef const float4 *cf4;
+    const float *P = a.params;
+    PRISM_STAMP(8);
+    // ---- per-wave constants: the W1 slice of the wave's columns as the B operand of dX (K = hidden unit), split once
+    Split3 w1p[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[j] = P[a.off.iqn_w1 + (int64_t)(32 * kb + 8 * g + j) * E_DIM + n];
+        w1p[kb] = split_bf16x3(wv);
+    }
+    const float g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
+    const __amdgpu_buffer_rsrc_t rs_ph = __builtin_amdgcn_make_buffer_rsrc(a.ws.phis, 0, ((R + 15) / 16) * 16 * E_DIM * 4, 0x00020000);
+    const int vo_ph = (4 * g * 16 + li) * 4;
+
+    f32x4 accWphi[4], accW1[NHT];      // accWphi[c][r]: dWphi[n = 16 cs + 4g + r][k = 16c + li];  accW1[ht][r]: dW1[h = 16ht + 4g + r][n]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accWphi[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
+
+    // ---- staging: 32 rows of dpre1 (4 float4 a thread) and of the cos basis (2), requested one block ahead
+    float4 pd[4], pc[2];
+    auto request = [&](int blk) __attribute__((always_inline)) {
+        const int r0 = row0 + blk * BW3_RB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            pd[i] = reinterpret_cast<cf4>(a.ws.dpre1 + (size_t)(r0 + (idx >> 5)) * H)[idx & 31];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            pc[i] = reinterpret_cast<cf4>(a.ws.cosb + (size_t)(r0 + (idx >> 4)) * K_BASIS)[idx & 15];
+        }
+    };
+    auto stage = [&](char *buf) __attribute__((always_inline)) {
+        char *PD = buf, *CS = buf + 3 * BW3_P;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const float x[4] = {pd[i].x, pd[i].y, pd[i].z, pd[i].w};
+            qb2_store4(PD, BW3_P, (idx >> 5) * BW3_PROW + 8 * (idx & 31), x);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const float x[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
+            qb2_store4(CS, BW3_C, (idx >> 4) * BW3_CROW + 8 * (idx & 15), x);
+        }
+    };
+    // per-wave row data of a block: saved ReLU(phi) of the wave's columns, LayerNorm row scalars, the samples' embeddings
+    struct RowData {
+        f32x4 ph[2], mu[2], rs[2], c1[2], c2[2];
+        float ev[2];
+    };
+    auto load_rows = [&](RowData &D, int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r0 = row0 + blk * BW3_RB + 16 * t;
+            const int so = ((r0 >> 4) * (E_DIM / 16) + cs) * 1024;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) D.ph[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ph, vo_ph + 64 * r, so, 0));
+            if (LN) {
+                D.mu[t] = *reinterpret_cast<const f32x4 *>(a.ws.mu1 + r0 + 4 * g);
+                D.rs[t] = *reinterpret_cast<const f32x4 *>(a.ws.rstd1 + r0 + 4 * g);
+                D.c1[t] = *reinterpret_cast<const f32x4 *>(a.ws.c1 + r0 + 4 * g);
+                D.c2[t] = *reinterpret_cast<const f32x4 *>(a.ws.c2 + r0 + 4 * g);
+            }
+            D.ev[t] = a.ws.e_cur[(int64_t)((r0 + 4 * g) / T) * E_DIM + n];
+        }
+    };
+    RowData D;
+    request(0);
+    load_rows(D, 0);
+    stage(smem);
+    lds_barrier();
+    PRISM_STAMP(9);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const char *cur = smem + (blk & 1) * BW3_BUF;
+        char *nxt = smem + ((blk + 1) & 1) * BW3_BUF;
+        const bool more = blk + 1 < nblk;
+        if (more) request(blk + 1);
+        const char *PD = cur, *CS = cur + 3 * BW3_P;
+        float xs8[8], dp8[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r0 = row0 + blk * BW3_RB + 16 * t;
+            // dX[m = 4g + r][n] = sum_h dpre1[m][h] W1[h][n]: A = the image's rows (eight consecutive hidden units a lane)
+            // (all operand reads of a phase are issued before its first MFMA: one LDS round trip a phase, not one a group --
+            // the wave is alone on its SIMD, there are registers to spare)
+            f32x4 adx = {0.f, 0.f, 0.f, 0.f};
+            u32x4 xa[4][3];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const char *ar = PD + (16 * t + li) * BW3_PROW + 64 * kb + 16 * g;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xa[kb][pl] = *reinterpret_cast<const u32x4 *>(ar + pl * BW3_P);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) adx = mfma_split(xa[kb][0], xa[kb][1], xa[kb][2], w1p[kb], adx);
+            // element-wise backward of the tile's rows 4g + r, column n (as iqn_bwd_kernel)
+            const float ev = D.ev[t];
+            float dep = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float phi = D.ph[t][r];
+                const float h0 = phi * ev;
+                const float xhat = LN ? (h0 - D.mu[t][r]) * D.rs[t][r] : h0;
+                xs8[4 * t + r] = LN ? xhat * g1 + be1 : h0;
+                const float dX = adx[r];
+                s_dg += dX * xhat;
+                s_db += dX;
+                const float dh0 = LN ? D.rs[t][r] * (dX * g1 - D.c1[t][r] * (1.0f / E_DIM) - xhat * (D.c2[t][r] * (1.0f / E_DIM))) : dX;
+                dep += dh0 * phi;
+                const float dpp = (phi > 0.f) ? dh0 * ev : 0.f;
+                dp8[4 * t + r] = dpp;
+                s_dbphi += dpp;
+            }
+            // d e[b][n]: sum over the T rows of a sample
+            const int bsm = (r0 + 4 * g) / T;
+            if (T == 4) {
+                a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+            } else if (T == 8) {
+                dep += __shfl_xor(dep, 16, 64);
+                if ((g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+            } else {
+                dep += __shfl_xor(dep, 16, 64);
+                dep += __shfl_xor(dep, 32, 64);
+                de_acc += dep;
+                if (((r0 + 16) % T) == 0) {
+                    if (g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
+                    de_acc = 0.f;
+                }
+            }
+        }
+        if (more) load_rows(D, blk + 1);          // (this block's row data is consumed)
+        const Split3 X = split_bf16x3(xs8), DP = split_bf16x3(dp8);
+        // dWphi[n][k] += sum_m dphi[m][n] cos[m][k]: A = dphi (own registers), B = cos by transposed reads
+        Split3 cb[4];
+        u32x4 wa[NHT][3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            cb[c].hi = bw3_tr_rows(CS, BW3_CROW, 16 * c, lane);
+            cb[c].mid = bw3_tr_rows(CS + BW3_C, BW3_CROW, 16 * c, lane);
+            cb[c].lo = bw3_tr_rows(CS + 2 * BW3_C, BW3_CROW, 16 * c, lane);
+        }
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wa[ht][pl] = bw3_tr_rows(PD + pl * BW3_P, BW3_PROW, 16 * ht, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accWphi[c] = mfma_split(DP.hi, DP.mid, DP.lo, cb[c], accWphi[c]);
+        // dW1[h][n] += sum_m dpre1[m][h] x[m][n]: A = dpre1 by transposed reads of the same image, B = x (own registers)
+#pragma unroll
+        for (int ht = 0; ht < NHT; ++ht) accW1[ht] = mfma_split(wa[ht][0], wa[ht][1], wa[ht][2], X, accW1[ht]);
+        if (more) stage(nxt);
+        lds_barrier();
+    }
+    PRISM_STAMP(10);
+    // ---- this wave's part of the chunk's slab: nobody else holds these columns
+    float *slab = a.ws.slabs + (int64_t)rc * a.slab;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            __builtin_nontemporal_store(accWphi[c][r], slab + (int64_t)(16 * cs + 4 * g + r) * K_BASIS + 16 * c + li);
+#pragma unroll
+    for (int ht = 0; ht < NHT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            __builtin_nontemporal_store(accW1[ht][r], slab + SLAB_W1 + (int64_t)(16 * ht + 4 * g + r) * E_DIM + n);
+    s_dg += __shfl_xor(s_dg, 16, 64);
+    s_dg += __shfl_xor(s_dg, 32, 64);
+    s_db += __shfl_xor(s_db, 16, 64);
+    s_db += __shfl_xor(s_db, 32, 64);
+    s_dbphi += __shfl_xor(s_dbphi, 16, 64);
+    s_dbphi += __shfl_xor(s_dbphi, 32, 64);
+    if (g == 0) {
+        slab[E_DIM * K_BASIS + n] = s_dbphi;
+        if (LN) {
+            slab[E_DIM * K_BASIS + E_DIM + n] = s_dg;
+            slab[E_DIM * K_BASIS + 2 * E_DIM + n] = s_db;
+        }
+    }
+    PRISM_STAMP(12);
+}
+
+}  // namespace prism

@@ -16,6 +16,7 @@
 #include "fwd_kernels.h"
 #include "act_kernels.h"
 #include "qbwd2_kernels.h"
+#include "bwd3_kernels.h"
 
 namespace prism {
 
@@ -72,7 +73,7 @@ struct Carver {
 // workgroups), or two workgroups per CU sharing each SIMD (8 row chunks; width 128 only).  Measured on MI355X
 // (configs[2]): 33.4 us vs 30.3 us -- one wave per SIMD cannot keep the matrix pipe fed through its own VALU and
 // hazard bubbles, the shared form is the default; PRISM_BWD_MODE=1 picks the first form for A/B runs.
-static constexpr int MAX_CHUNKS = 8;
+static constexpr int MAX_CHUNKS = 16;
 static int bwd_mode() {
     static const int mode = [] { const char *e = getenv("PRISM_BWD_MODE"); return e ? atoi(e) : 0; }();
     return mode;
@@ -102,6 +103,14 @@ static int use_split(const prism_learner_desc *ld) {
     if (d.use_iqn && d.iqn_width != 128) return 0;
     if (d.n_heads && d.head_layers == 2 && d.head_width != 128) return 0;
     return (d.use_iqn || (d.n_heads && d.head_layers == 2)) ? 1 : 0;
+}
+
+// the 64-column bf16 backward (bwd3_kernels.h) where it applies: bf16 mode, width 128 (the forward then saves ReLU(phi))
+static bool use_bw3(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    static const bool off = [] { const char *e = getenv("PRISM_NO_BWD3"); return e && atoi(e) != 0; }();
+    // (models with Q heads only: IQN-only models carry their conv-backward taps in iqn_bwd_kernel, bwd3_kernels.h)
+    return !off && d.use_iqn && d.n_heads > 0 && use_split(ld) && bw3_ok(d.iqn_width, ld->batch, d.n_tau, true);
 }
 
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
@@ -268,6 +277,7 @@ static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 
 
 static bool conv_in_bwd(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
+    if (use_bw3(ld)) return false;
     return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, bwd_chunks(iqn_width(d)),
                        iqn_width(d));
 }
@@ -296,7 +306,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.ln = d.use_layer_norm;
     a.slab = iqn_slab_floats(a.Hi, a.ln);
     a.q_slab = q_slab_floats(a.Hq, a.ln);
-    a.n_chunks = bwd_chunks(a.Hi);
+    a.n_chunks = use_bw3(ld) ? BW3_RC : bwd_chunks(a.Hi);
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
@@ -615,7 +625,23 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         }
         PRISM_CHECK_LAUNCH();
     }
-    if (ld->dims.use_iqn) {
+    if (ld->dims.use_iqn && use_bw3(ld)) {
+        ProfileScope ps_(K_BWD, stream);
+        const dim3 grid((E_DIM / 64) * BW3_RC);
+        const size_t lds = BW3_LDS_BYTES;
+        if (a.ln) {
+            herr = set_max_lds((const void *)iqn_bwd3_kernel<true>, lds);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<true>), grid, dim3(256), lds, stream, a);
+        } else {
+            herr = set_max_lds((const void *)iqn_bwd3_kernel<false>, lds);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<false>), grid, dim3(256), lds, stream, a);
+        }
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(iqn_bwd3): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
+        PRISM_CHECK_LAUNCH();
+    } else if (ld->dims.use_iqn) {
         if (!bwd_lds_layout_ok(a.Hi, B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0)) {
             set_error("prism_learner_fwd_bwd: internal: LDS layout of the backward kernel overlaps for this shape");
             return PRISM_ERR_INVALID;

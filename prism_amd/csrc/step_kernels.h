@@ -738,13 +738,15 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 const int i = blk * 1024 + tid;
                 PRISM_STAMP(8);
                 if (i < a.slab / 4) {
+                    // every chunk's partial requested before the first add (sixteen chunks from the 64-column backward,
+                    // eight or four from the 16-column one), then summed in chunk order
                     float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
-                    float4 v[7];
+                    float4 v[15];
 #pragma unroll
-                    for (int c = 1; c < 8; ++c)
+                    for (int c = 1; c < 16; ++c)
                         if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * a.slab)[i];
 #pragma unroll
-                    for (int c = 1; c < 8; ++c)
+                    for (int c = 1; c < 16; ++c)
                         if (c < a.n_chunks) {
                             s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
                         }
