@@ -259,23 +259,26 @@ __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int set, int h, i
 // (conv_w_slot maps a flat weight index to its LDS slot): three 16-byte reads per pair instead of nine.
 constexpr int CONV_W_PAD = 12;
 __device__ __forceinline__ int conv_w_slot(int i) { return (i / 9) * CONV_W_PAD + i % 9; }
+// NW waves take part (4 or 8): wave w0 = the output channels w0, w0 + NW, ...; `tid` counts from the first of them.
+template <int NW = 4>
 __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
                                                 float *__restrict__ dst, int tid, int nthreads) {
-    // thread = output position (y, x) x a group of four output channels c0, c0 + 4, c0 + 8, c0 + 12:
-    // the 3x3 input patch of a channel is read once and feeds all four (their weight reads are
+    // thread = output position (y, x) x a group of 16 / NW output channels c0, c0 + NW, ...:
+    // the 3x3 input patch of a channel is read once and feeds all of them (their weight reads are
     // wave-uniform broadcasts).  Per output the fmaf chain runs (ci, dy, dx)-major from zero and the bias is added to the
     // finished sum (accumulating ONTO a large bias rounds at the bias's magnitude 9 C times: tests/test_gpu_ln_stress.py).
+    constexpr int NCH = 16 / NW;
     const int c0 = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
-    float acc[4];
+    float acc[NCH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
     for (int ci = 0; ci < C; ++ci) {
         float p[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) p[t] = s_obs[((y + t / 3) * 10 + (x + t % 3)) * C + ci];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 *w4 = reinterpret_cast<const float4 *>(s_w + ((c0 + 4 * k) * C + ci) * CONV_W_PAD);
+        for (int k = 0; k < NCH; ++k) {
+            const float4 *w4 = reinterpret_cast<const float4 *>(s_w + ((c0 + NW * k) * C + ci) * CONV_W_PAD);
             const float4 wa = w4[0], wb = w4[1], wc = w4[2];
             const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
 #pragma unroll
@@ -283,8 +286,9 @@ __device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float 
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(fmaxf(acc[k] + s_b[c0 + 4 * k], 0.f), &dst[(c0 + 4 * k) * 64 + (tid & 63)]);
-    (void)nthreads;     // (256 threads: E_DIM / 4 positions-by-group)
+    for (int k = 0; k < NCH; ++k)
+        __builtin_nontemporal_store(fmaxf(acc[k] + s_b[c0 + NW * k], 0.f), &dst[(c0 + NW * k) * 64 + (tid & 63)]);
+    (void)nthreads;
 }
 
 __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red);

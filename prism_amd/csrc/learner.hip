@@ -910,7 +910,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     {
         ProfileScope ps_(K_FRONT, stream);
         hipLaunchKernelGGL(step_front_kernel,
-                           dim3(ld->batch + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a, *rp, f);
+                           dim3(ld->batch + front_extra_blocks(extra_dims(a))), dim3(FRONT_THREADS), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

@@ -108,7 +108,12 @@ struct FrontArgs {
 // blocks [0, B): one sample each — tree descent, n-step walk, row gather, conv3x3+ReLU of both
 // observations;  blocks [B, B + H/4): u = W1 g1, v = W1 beta1;  then PACK_BLOCKS (x2 with a target
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
-__global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
+// 512 threads: waves 0-3 as before (wave 0 samples, waves 1-3 stage the conv weights); waves 4-7 convolve the CURRENT
+// observation while lane 0 of wave 0 walks the n-step links (three dependent loads), and all eight waves convolve the
+// successor once its row has arrived.  Sequential form (256 threads): walk 3.8 k + both convolutions 7.5 k cycles behind
+// the sampled index; now walk ‖ first convolution, then the second at two output channels a wave.
+constexpr int FRONT_THREADS = 512;
+__global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
     kernarg_prefetch<sizeof(IqnArgs) + sizeof(prism_replay_desc) + sizeof(FrontArgs)>();
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ __attribute__((aligned(16))) float s_scratch[256];
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= B) {
+        if (tid >= 256) return;                  // (the parameter-only roles are 256-thread routines)
         PRISM_STAMP(27);
         front_extra_block(a, b - B, s_scratch);
         PRISM_STAMP(31);
@@ -139,7 +145,9 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
     const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
     constexpr int TOP_PER_LANE = (TOP_NODES + 63) / 64, W_PER_THREAD = 8;       // 16 * 10 * 9 = 1440 weights <= 8 * 192
     int64_t idx;
-    if (tid >= 64) {
+    if (tid >= 256) {
+        // (waves 4-7: nothing to fetch)
+    } else if (tid >= 64) {
         const int t = tid - 64;
         float wr[2][W_PER_THREAD], br[2] = {0.f, 0.f};
 #pragma unroll
@@ -229,16 +237,21 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
         s_i64[0] = idx;
     }
     PRISM_STAMP(29);
-    // The sampled slot is known: every thread requests its piece of the CURRENT observation now, so that the row is
-    // on its way while thread 0 walks the n-step links (three dependent loads); the successor row can only be
-    // requested behind the walk, and lands while the first row is being convolved.  (O / 4 = 25 C <= 250 pieces.)
+    // The sampled slot is known: the first O / 4 threads request their piece of the CURRENT observation, park it in LDS and
+    // stream it to the static batch; behind the next barrier waves 4-7 convolve it while lane 0 of wave 0 walks the links.
     __syncthreads();
     const int O = rp.obs_elems;     // == 100 * C
     const float *src_obs = rp.obs + s_i64[0] * O;
     float *d0 = f.obs + (int64_t)b * O, *d1 = f.next_obs + (int64_t)b * O;
-    float4 xc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < O / 4) xc = reinterpret_cast<const float4 *>(src_obs)[tid];
-    if (tid == 0) {
+    if (tid < O / 4) {
+        const float4 xc = reinterpret_cast<const float4 *>(src_obs)[tid];
+        stream_store4(reinterpret_cast<float4 *>(d0) + tid, xc);
+        reinterpret_cast<float4 *>(s_obs[0])[tid] = xc;
+    }
+    lds_barrier();
+    if (tid >= 256) {
+        conv_embed_rows<4>(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid - 256, 256);
+    } else if (tid == 0) {
         const NStepResult ns = nstep_walk(rp, idx);
         s_i64[1] = ns.last;
         s_flags = ns.flags;
@@ -251,26 +264,20 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
             f.out_weight[b] = s_out_w;
             if (b == 0 || s_rec_state == 2u) atomicMax(a.ws.ticket + 3, s_rec_state);
         }
+    } else if (f.use_per && tid >= 64 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity)) {
+        // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
+        reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
     }
     PRISM_STAMP(30);
-    if (tid < O / 4) {
-        stream_store4(reinterpret_cast<float4 *>(d0) + tid, xc);
-        reinterpret_cast<float4 *>(s_obs[0])[tid] = xc;
-    }
-    __syncthreads();
-    // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
-    if (f.use_per && tid >= 64 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity))
-        reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
+    lds_barrier();
     const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
-    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < O / 4) xn = reinterpret_cast<const float4 *>(src_next)[tid];
-    conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);
     if (tid < O / 4) {
+        const float4 xn = reinterpret_cast<const float4 *>(src_next)[tid];
         stream_store4(reinterpret_cast<float4 *>(d1) + tid, xn);
         reinterpret_cast<float4 *>(s_obs[1])[tid] = xn;
     }
-    __syncthreads();
-    conv_embed_rows(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
+    lds_barrier();
+    conv_embed_rows<8>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 512);
     PRISM_STAMP(31);
 }
 
@@ -454,13 +461,20 @@ __device__ __forceinline__ bool grid_barrier_wait(unsigned long long *bar, unsig
         const unsigned long long target = ((old >> 20) + 1ull) << 20;
         int ok = 1;
         if (old + grid_barrier_weight(n) < target) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            // (the clock is read once every 256 polls: a read of the real-time counter in EVERY iteration made the waiter
+            // notice the last arrival later -- tail launch 14.0 -> 15.2 us)
+            unsigned long long t0 = 0;
+            unsigned int polls = 0;
             while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > GRID_WAIT_TICKS) {
-                    ok = 0;
-                    atomicOr(status, GRID_STATUS_TIMEOUT);
-                    break;
+                if ((++polls & 255u) == 0u) {
+                    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > GRID_WAIT_TICKS) {
+                        ok = 0;
+                        atomicOr(status, GRID_STATUS_TIMEOUT);
+                        break;
+                    }
                 }
             }
         }

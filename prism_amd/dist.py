@@ -45,7 +45,7 @@ class DirectAllReduce:
     """The step's gradient all-reduce without RCCL: two shots over peer-mapped buffers (``prism_direct_reduce_scatter`` /
     ``prism_direct_all_gather``, include/prism_hip.h).  Every rank pulls its 1/world slice of the
     flat gradient from all peers at once and sums it in rank order, then pulls the other slices from their owners: all
-    replicas hold bit-identical sums.  ``config.collective = "direct"`` selects it; RCCL stays the default and the oracle.
+    replicas hold bit-identical sums.  ``config.collective = "direct"`` selects it; RCCL stays the default and the yardstick it is tested against.
 
     The peers' buffers are mapped with torch's CUDA-IPC tensor sharing (``hipIpcGetMemHandle`` / ``hipIpcOpenMemHandle``
     underneath; needs ``HSA_ENABLE_IPC_MODE_LEGACY=0`` on this stack), the handles travel through ``all_gather_object`` of

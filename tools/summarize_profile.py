@@ -51,6 +51,7 @@ tpath = os.path.join(dst, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 traffic[cfg] = {k: int((2 * fetch[k] + write.get(k, 0.0)) * 1024) for k in fetch if "init" not in k and "rebuild" not in k}
 traffic[cfg + "_raw_KiB"] = {k: {"FETCH_SIZE": round(fetch[k], 1), "WRITE_SIZE": round(write.get(k, 0.0), 1)} for k in traffic[cfg]}
+traffic.setdefault("_meta", {})[cfg] = tag          # which profile run the figures of this configuration come from
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
 line = [ln for ln in open(os.path.join(src, "stats.log")) if ln.startswith("{")]
 if line:
