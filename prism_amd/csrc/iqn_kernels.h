@@ -365,7 +365,7 @@ template <int H>
 __host__ __device__ constexpr int loss_lds_floats() { return LossLds<H>::TOTAL; }
 
 template <int H, bool LN, int LW>
-__global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) {
+__device__ __forceinline__ void iqn_loss_body(const IqnArgs &a, const int b) {
     constexpr int LOSS_WAVES = LW, LOSS_RPW = 64 / LW;     // rows per wave (T <= 64)
     constexpr int KH = H / 64, AS = 2 * H + 4;
     __shared__ __attribute__((aligned(16))) float lds[loss_lds_floats<H>()];
@@ -374,7 +374,6 @@ __global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) {
     float *s_zc = lds + LD::ZC.off, *s_zo = lds + LD::ZO.off, *s_zt = lds + LD::ZT.off;
     float *s_y = lds + LD::Y.off, *s_q = lds + LD::Q.off, *s_tau = lds + LD::TAU.off, *s_dq = lds + LD::DQ.off;
     float *s_acc = lds + LD::ACC.off;             // [LOSS_WAVES][AS]
-    const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, T = a.T, Tn = a.Tn;
     const float kap = a.huber_k;
@@ -536,6 +535,8 @@ __global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) {
         else a.ws.Db[b] = t;
     }
 }
+template <int H, bool LN, int LW>
+__global__ __launch_bounds__(64 * LW) void iqn_loss_kernel(IqnArgs a) { iqn_loss_body<H, LN, LW>(a, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // bwd: grid = (E/16 column slices) x n_chunks row chunks, 256 threads = 4 waves; each wave walks a contiguous

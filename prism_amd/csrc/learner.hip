@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void step_back_kernel(AdamArgs a, prism_replay
     clip_adam_block<256>(a, blockIdx.x - 1, gridDim.x - 1);
 }
 
+// Models with both parts (IDS: IQN + Q ensemble): the two per-sample losses in ONE launch -- blocks [0, B) the quantile
+// loss, [B, 2 B) the ensemble loss (both 512-thread routines; neither reads what the other writes: td = dl / 2 + ql / 2 is
+// combined by the post launch).  Two latency-bound launches and a boundary become one.
+template <int H, bool LN>
+__global__ __launch_bounds__(512) void loss_both_kernel(IqnArgs a) {
+    if ((int)blockIdx.x < a.B) iqn_loss_body<H, LN, LOSS_WAVES>(a, blockIdx.x);
+    else qh_loss_body<H, LN>(a, (int)blockIdx.x - a.B);
+}
+
 // ---- workspace carving -----------------------------------------------------------------------
 struct Carver {
     char *base;
@@ -215,7 +224,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
         w.q_slabs = c.f(Hd * (size_t)q_slab_floats((int)Hq, ln));
     }
     float *tb = c.f(3 * maxT * B);
-    float *db = c.f(B);
+    float *db = c.f(2 * (size_t)B);       // per-sample dl | ql when the caller binds no output arrays (the post launch reads both)
     if (ws) *ws = w;
     if (tau_buf) *tau_buf = tb;
     if (dl_buf) *dl_buf = db;
@@ -342,7 +351,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.tau_out = ld->tau_out ? ld->tau_out : tau_buf;
     a.maxT = d.n_tau > d.n_tau_next ? d.n_tau : d.n_tau_next;
     a.out_dl = ld->out_dist_loss ? ld->out_dist_loss : dl_buf;
-    a.out_ql = ld->out_q_loss ? ld->out_q_loss : dl_buf;
+    a.out_ql = ld->out_q_loss ? ld->out_q_loss : dl_buf + B;
     a.out_td = ld->out_td;
     a.out_scalars = ld->out_scalars;
     a.grads = ld->grads;
@@ -603,7 +612,16 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         PRISM_CHECK_LAUNCH();
     }
     // losses first (TD errors final), then the backward kernels
-    if (ld->dims.use_iqn && !a.local_loss) {
+    const bool merged_loss = ld->dims.use_iqn && !a.local_loss && ld->dims.n_heads > 0 && ld->dims.head_layers == 2 && a.Hi == a.Hq &&
+                             loss_waves(a.T) == LOSS_WAVES;
+    if (merged_loss) {
+        ProfileScope ps_(K_LOSS, stream);
+        dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
+            hipLaunchKernelGGL((loss_both_kernel<decltype(h)::value, decltype(l)::value>), dim3(2 * B), dim3(512), 0, stream, a);
+        });
+        PRISM_CHECK_LAUNCH();
+    }
+    if (ld->dims.use_iqn && !a.local_loss && !merged_loss) {
         ProfileScope ps_(K_LOSS, stream);
         dispatch_hl(a.Hi, a.ln, [&](auto h, auto l) {
             if (loss_waves(a.T) == 16)
@@ -614,7 +632,7 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         });
         PRISM_CHECK_LAUNCH();
     }
-    if (ld->dims.n_heads > 0) {
+    if (ld->dims.n_heads > 0 && !merged_loss) {
         ProfileScope ps_(K_Q_FWD, stream);
         if (ld->dims.head_layers == 1) {
             hipLaunchKernelGGL(dqn_loss_kernel, dim3(B), dim3(256), 0, stream, a);
@@ -909,8 +927,11 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     f.action = const_cast<int64_t *>(ld->action);
     {
         ProfileScope ps_(K_FRONT, stream);
-        hipLaunchKernelGGL(step_front_kernel,
-                           dim3(ld->batch + front_extra_blocks(extra_dims(a))), dim3(FRONT_THREADS), 0, stream, a, *rp, f);
+        const int extra = front_extra_blocks(extra_dims(a));
+        if (front_threads(ld->batch, extra) == 512)
+            hipLaunchKernelGGL(step_front_kernel<512>, dim3(ld->batch + extra), dim3(512), 0, stream, a, *rp, f);
+        else
+            hipLaunchKernelGGL(step_front_kernel<256>, dim3(ld->batch + extra), dim3(256), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

@@ -122,12 +122,12 @@ __device__ __forceinline__ void stage_head_norms(const IqnArgs &a, float *s_part
 // head + LayerNorm(H) backward of the sample's row in every head.
 // ------------------------------------------------------------------------------------------
 template <int H, bool LN>
-__global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
+__device__ __forceinline__ void qh_loss_body(const IqnArgs &a, const int b) {
     constexpr int KH = H / 64;
     __shared__ float s_zc[Q_MAX_HEADS * 16], s_zo[Q_MAX_HEADS * 16], s_zt[Q_MAX_HEADS * 16];
     __shared__ float s_dq[Q_MAX_HEADS], s_sq[Q_MAX_HEADS];
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int B = a.B, A = a.A, Hd = a.n_heads;
     // saved activations of this wave's rows (heads w, w + 8): in flight before the loss is known
     float xa[2][KH], pa[2][KH], rs[2];
@@ -186,8 +186,9 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         const float ql = a.q_w * (s - theil * a.theil_coef);
         a.out_ql[b] = ql;
         a.ws.q_lossw[b] = ql * wb;
-        // td errors (composite_model.py:135-142)
-        a.out_td[b] = a.use_iqn ? (a.out_dl[b] * 0.5f + ql * 0.5f) : fabsf(ql);
+        // td errors (composite_model.py:135-142): |ql| for a Q-only model; with an IQN part the post launch combines
+        // dl / 2 + ql / 2 (this kernel runs beside the IQN loss, not behind it)
+        if (!a.use_iqn) a.out_td[b] = fabsf(ql);
         if (b == 0) a.out_scalars[4] = theil;
     }
     if (a.q_pieces) {
@@ -264,6 +265,9 @@ __global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) {
         }
     }
 }
+
+template <int H, bool LN>
+__global__ __launch_bounds__(512) void qh_loss_kernel(IqnArgs a) { qh_loss_body<H, LN>(a, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------
 // q bwd: grid = (E/16 column slices) x heads, 256 threads = 4 waves, each wave a strided set of the

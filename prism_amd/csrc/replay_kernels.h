@@ -462,7 +462,14 @@ template <bool PREPARE_ONLY = false, bool DENSE = false>
 __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, const int64_t *__restrict__ index,
                                  const float *__restrict__ priority, int n, float alpha, float eps, int take_abs,
                                  char *lds, const float2 *__restrict__ sib = nullptr, int sib_stride = 0,
-                                 int4 *__restrict__ plan_out = nullptr, int live_threads = 0) {
+                                 int4 *__restrict__ plan_out = nullptr, int live_threads = 0,
+                                 const float *__restrict__ priority2 = nullptr) {
+    // `priority2` (optional): the priority of element i is 0.5 priority[i] + 0.5 priority2[i] -- the TD error of a model with
+    // both a distributional and a Q part, td = dl / 2 + ql / 2 (composite_model.py:135-137), taken from the two per-sample
+    // losses where nobody has combined them yet (same expression, same bits)
+    auto prio = [&](int i) __attribute__((always_inline)) {
+        return priority2 ? priority[i] * 0.5f + priority2[i] * 0.5f : priority[i];
+    };
     float *s_red = reinterpret_cast<float *>(lds + PU_RED.off);
     const int tid = threadIdx.x;
     // `live_threads` (a multiple of 64, >= n rounded up): the caller has already retired the waves above it -- a
@@ -476,14 +483,14 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
     int32_t me = 0;
     float p0 = 0.f;
     if (tid < min(pass, n)) {
-        p0 = priority[tid];
+        p0 = prio(tid);
         if (take_abs) p0 = fabsf(p0);
         me = (int32_t)index[tid];
     }
     // running max of the raw priorities (torchrl tracks it before the +eps, **alpha)
     float m = tid < min(pass, n) ? p0 : -FLT_MAX;
     for (int i = pass + tid; i < n; i += bd) {
-        float p = priority[i];
+        float p = prio(i);
         if (take_abs) p = fabsf(p);
         m = fmaxf(m, p);
     }
@@ -496,7 +503,7 @@ __device__ __forceinline__ void per_update_block(const prism_replay_desc &rp, co
         if (base) {
             __syncthreads();                                    // previous pass: stores drained, LDS free
             if (tid < cnt) {
-                p0 = priority[base + tid];
+                p0 = prio(base + tid);
                 if (take_abs) p0 = fabsf(p0);
                 me = (int32_t)index[base + tid];
             }

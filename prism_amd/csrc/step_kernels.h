@@ -112,8 +112,12 @@ struct FrontArgs {
 // observation while lane 0 of wave 0 walks the n-step links (three dependent loads), and all eight waves convolve the
 // successor once its row has arrived.  Sequential form (256 threads): walk 3.8 k + both convolutions 7.5 k cycles behind
 // the sampled index; now walk ‖ first convolution, then the second at two output channels a wave.
-constexpr int FRONT_THREADS = 512;
-__global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
+// NT = 256 is the sequential form, kept for the configurations whose launch is mostly parameter-only blocks (ten Q heads
+// and a target network: ~1500 packing blocks beside 512 sample blocks -- half-empty 512-thread workgroups cost that launch
+// 5 us): the host picks by block counts (front_threads).
+__host__ __device__ inline int front_threads(int B, int extra_blocks) { return extra_blocks <= B ? 512 : 256; }
+template <int NT>
+__global__ __launch_bounds__(NT) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
     kernarg_prefetch<sizeof(IqnArgs) + sizeof(prism_replay_desc) + sizeof(FrontArgs)>();
     __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ __attribute__((aligned(16))) float s_scratch[256];
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, pr
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= B) {
-        if (tid >= 256) return;                  // (the parameter-only roles are 256-thread routines)
+        if (NT > 256 && tid >= 256) return;      // (the parameter-only roles are 256-thread routines)
         PRISM_STAMP(27);
         front_extra_block(a, b - B, s_scratch);
         PRISM_STAMP(31);
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, pr
     const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
     constexpr int TOP_PER_LANE = (TOP_NODES + 63) / 64, W_PER_THREAD = 8;       // 16 * 10 * 9 = 1440 weights <= 8 * 192
     int64_t idx;
-    if (tid >= 256) {
+    if (NT > 256 && tid >= 256) {
         // (waves 4-7: nothing to fetch)
     } else if (tid >= 64) {
         const int t = tid - 64;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, pr
         reinterpret_cast<float4 *>(s_obs[0])[tid] = xc;
     }
     lds_barrier();
-    if (tid >= 256) {
+    if (NT > 256 && tid >= 256) {
         conv_embed_rows<4>(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid - 256, 256);
     } else if (tid == 0) {
         const NStepResult ns = nstep_walk(rp, idx);
@@ -264,20 +268,23 @@ __global__ __launch_bounds__(FRONT_THREADS) void step_front_kernel(IqnArgs a, pr
             f.out_weight[b] = s_out_w;
             if (b == 0 || s_rec_state == 2u) atomicMax(a.ws.ticket + 3, s_rec_state);
         }
-    } else if (f.use_per && tid >= 64 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity)) {
+    } else if (f.use_per && tid >= 64 && tid < 256 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity)) {
         // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
         reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
     }
     PRISM_STAMP(30);
     lds_barrier();
     const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
+    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < O / 4) xn = reinterpret_cast<const float4 *>(src_next)[tid];
+    if (NT == 256) conv_embed_rows<4>(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);     // (beside the successor row's flight)
     if (tid < O / 4) {
-        const float4 xn = reinterpret_cast<const float4 *>(src_next)[tid];
         stream_store4(reinterpret_cast<float4 *>(d1) + tid, xn);
         reinterpret_cast<float4 *>(s_obs[1])[tid] = xn;
     }
     lds_barrier();
-    conv_embed_rows<8>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 512);
+    if (NT == 256) conv_embed_rows<4>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
+    else conv_embed_rows<8>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 512);
     PRISM_STAMP(31);
 }
 
@@ -637,15 +644,19 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     __shared__ float s_red[64];
     PRISM_STAMP(13);
     if (wb.enabled && (int)blockIdx.x == wb.block) {
+        // (models with both parts: td = dl / 2 + ql / 2 is combined HERE from the two losses -- out_td is written by another
+        // block of this launch, the Q loss no longer reads the IQN loss's output: the two loss kernels are one launch)
+        const bool both = a.use_iqn && a.n_heads > 0;
+        const float *pr = both ? a.out_dl : a.out_td, *pr2 = both ? a.out_ql : nullptr;
         if (!WB_FULL) {
-            per_update_block<true>(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool, nullptr, 0, wb.plan);
+            per_update_block<true>(wb.rp, wb.index, pr, a.B, wb.alpha, wb.eps, 1, s_pool, nullptr, 0, wb.plan, 0, pr2);
         } else {
             const unsigned int rec = wb.sib_state ? *wb.sib_state : 0u;
             // waves the batch does not need leave now (one pass: B <= 512)
             const int live = a.B <= UPD_MAX ? min(1024, 2 * ((a.B + 63) & ~63)) : 0;     // (x2: the ranking splits its count two ways)
             if (live && (int)threadIdx.x >= live) return;
-            per_update_block<false, DENSE>(wb.rp, wb.index, a.out_td, a.B, wb.alpha, wb.eps, 1, s_pool,
-                                           rec == 1u ? wb.sib : nullptr, a.B, nullptr, live);
+            per_update_block<false, DENSE>(wb.rp, wb.index, pr, a.B, wb.alpha, wb.eps, 1, s_pool,
+                                           rec == 1u ? wb.sib : nullptr, a.B, nullptr, live, pr2);
             if (wb.sib_state && threadIdx.x == 0) *wb.sib_state = 0u;  // (every thread read it before its first barrier)
         }
         if (TAIL && tl.rng && threadIdx.x == 0) {
@@ -815,7 +826,10 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 if (x == 0) {
                     for (int b = tid; b < B; b += 1024) {
                         lw += a.ws.q_lossw[b];
-                        if (a.use_iqn) li += a.ws.lossw[b];
+                        if (a.use_iqn) {
+                            li += a.ws.lossw[b];
+                            a.out_td[b] = a.out_dl[b] * 0.5f + a.out_ql[b] * 0.5f;      // td errors (composite_model.py:135-137)
+                        }
                     }
                 }
                 q_small_tensor_block(a, x / nqsm, x % nqsm, kappa, sq,
