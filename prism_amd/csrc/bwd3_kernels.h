@@ -12,10 +12,12 @@
 //                    dW1 by transposed reads of the same image, cos as the B operand of dWphi by transposed reads; the
 //                    element-wise results (dphi, x: 8 values a lane) are split in registers and ARE the remaining operands
 //                    (K index = the block's rows in accumulator order: two transposed reads at rows 4g and 16 + 4g).
-// Used for the models with Q heads (their conv backward is a role of the post launch anyway).  For IQN-only models
-// iqn_bwd_kernel stays: its conv-backward taps ride behind its tile loop, and carrying them here (measured: taps in this
-// kernel's loop, observation rows by LDS-DMA) cost what the faster products gained -- 25.8 us against 27.1 with the tail
-// launch 1.6 us longer over sixteen gradient slabs instead of eight.
+// Eight waves, two teams.  Waves 0-3 compute (the matrix work and the element-wise step of their 16 columns).  Waves 4-7 help:
+// they stage the NEXT block (fetch, split, park) while the computing waves work on the current one, and -- IQN-only models
+// -- accumulate the conv-backward taps of the PREVIOUS block from the ReLU-masked d e values their partner wave left in LDS
+// (observation rows by LDS-DMA, as in iqn_bwd_kernel).  Vector work of one team issues beside the MFMAs of the other: with
+// everything on four waves (one per SIMD) a block took 6.9 k cycles and the taps another 1.1 k (measured); the taps alone
+// made that form break even with iqn_bwd_kernel.
 // No cross-wave reduction: a wave owns its columns over all rows of the chunk.  Per 32 x 16 block and wave: 120 bf16 MFMAs
 // (1920 cycles, half of them open to vector issue) and ~450 vector instructions, against 160 fp32 MFMAs (5120) + ~900.
 // L2 traffic per row operand byte drops four-fold (64 columns per fetch instead of 16).
@@ -30,11 +32,25 @@ constexpr int BW3_RC = 16;                        // row chunks (gradient slabs)
 constexpr int BW3_PROW = 2 * 128 + 32, BW3_CROW = 2 * 64 + 32;      // LDS row strides (bytes): transposed reads conflict-free
 constexpr int BW3_P = BW3_RB * BW3_PROW, BW3_C = BW3_RB * BW3_CROW;  // one plane
 constexpr int BW3_BUF = 3 * (BW3_P + BW3_C);
-constexpr int BW3_LDS_BYTES = 2 * BW3_BUF;
-constexpr LdsRegion BW3_REGIONS[] = {{0, 3 * BW3_P, 1u}, {3 * BW3_P, 3 * BW3_C, 1u}, {BW3_BUF, 3 * BW3_P, 1u}, {BW3_BUF + 3 * BW3_P, 3 * BW3_C, 1u}};
+constexpr int BW3_DCV = 2 * 4 * 2 * 64 * 4;        // [block parity][slice][tile][lane] ReLU-masked d e, compute -> helper waves (bytes)
+constexpr int BW3_LDS_BYTES = 2 * BW3_BUF + BW3_DCV;
+constexpr LdsRegion BW3_REGIONS[] = {{0, 3 * BW3_P, 1u}, {3 * BW3_P, 3 * BW3_C, 1u}, {BW3_BUF, 3 * BW3_P, 1u}, {BW3_BUF + 3 * BW3_P, 3 * BW3_C, 1u},
+                                     {2 * BW3_BUF, BW3_DCV, 1u}};
 static_assert(lds_layout_ok(BW3_REGIONS, BW3_LDS_BYTES), "backward (bf16): LDS images overlap");
 static_assert(BW3_PROW % 16 == 0 && BW3_CROW % 16 == 0, "16-byte aligned image rows");
 
+// conv-backward taps (IQN-only models): behind the fixed regions, per helper wave the observation rows [samples][4 rows][10][C]
+// of the chunk's samples, then the lane-group partial sums [4 waves][4 groups][TAPS + 1]
+__host__ __device__ inline int bw3_samples(int B, int T) { return (B * T / BW3_RC) / T; }
+__host__ __device__ inline int bw3_lds_bytes(int B, int T, int C, bool conv) {
+    return BW3_LDS_BYTES + (conv ? 4 * (4 * bw3_samples(B, T) * 40 * C + 4 * 4 * (BWD_CONV_TAPS + 1)) : 0);
+}
+inline bool bw3_conv_ok(int use_iqn, int n_heads, int propagate_grad, int T, int C, int B) {
+    const int share = bwd_conv_share(T);
+    return use_iqn && n_heads == 0 && propagate_grad && T >= 8 && C % share == 0 && 9 * (C / share) <= BWD_CONV_TAPS && C / share <= 2 &&
+           (C / share == 1 || C % 2 == 0) && 9 * C < BWD_CONV_ROW && bw3_samples(B, T) * 10 * C <= 16 * 64 &&
+           bw3_lds_bytes(B, T, C, true) <= 160 * 1024;
+}
 inline bool bw3_ok(int H, int B, int T, bool phi_saved) { return H == BW3_H && phi_saved && (B * T) % (BW3_RC * BW3_RB) == 0 && ((B * T) / BW3_RC) % T == 0; }
 
 // 16x16x32 operand whose K index runs over the block's rows in ACCUMULATOR order (k = (g, j): row 4 g + j for j < 4, row
@@ -49,21 +65,137 @@ __device__ __forceinline__ u32x4 bw3_tr_rows(const char *plane, int row_bytes, i
 }
 
 template <bool LN>
-__global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
+__global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
     kernarg_prefetch<sizeof(IqnArgs)>();
     constexpr int H = BW3_H, NHT = H / 16;
     constexpr int SLAB_W1 = E_DIM * K_BASIS + E_DIM + (LN ? 2 * E_DIM : 0);
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     char *smem = reinterpret_cast<char *>(smem_f);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int team = w >> 2, wq = w & 3, ht_tid = tid & 255;       // team 0 computes, team 1 helps; wq: the 16-column slice of the group
     // (the row chunk in the low bits of the index: the 16 column groups of a chunk share an XCD, i.e. one L2 holds its rows)
     const int rc = blockIdx.x % BW3_RC, cg = blockIdx.x / BW3_RC;
-    const int n = 64 * cg + 16 * w + li, cs = 4 * cg + w;           // this lane's embed column; the wave's 16-column slice
+    const int n = 64 * cg + 16 * wq + li, cs = 4 * cg + wq;         // this lane's embed column; the wave's 16-column slice
     const int T = a.T, R = a.B * T, rpc = R / BW3_RC, row0 = rc * rpc, nblk = rpc / BW3_RB;
     typedef const float4 *cf4;
     const float *P = a.params;
+    float *s_dcv = reinterpret_cast<float *>(smem + 2 * BW3_BUF);    // [parity][slice][tile][64]
     PRISM_STAMP(8);
-    // ---- per-wave constants: the W1 slice of the wave's columns as the B operand of dX (K = hidden unit), split once
+    if (team == 1) {
+        // =============================== helper waves: staging + conv taps ===============================
+        const int C = a.C, y0 = (cs & 3) * 2;
+        const int share = bwd_conv_share(T), cpl = a.conv_in_bwd ? C / share : 0, n_mine = 9 * cpl;
+        const int sub = T == 8 ? (g & 1) : g;
+        const int ws_lo = row0 / T, ws_n = n_mine ? rpc / T : 0;
+        float *s_obs = reinterpret_cast<float *>(smem + BW3_LDS_BYTES) + wq * (ws_n * 40 * C);
+        float *s_tap = reinterpret_cast<float *>(smem + BW3_LDS_BYTES) + 4 * (ws_n * 40 * C);
+        float4 pd[4], pc[2];
+        auto request = [&](int blk) __attribute__((always_inline)) {
+            const int r0 = row0 + blk * BW3_RB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = ht_tid + 256 * i;
+                pd[i] = reinterpret_cast<cf4>(a.ws.dpre1 + (size_t)(r0 + (idx >> 5)) * H)[idx & 31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = ht_tid + 256 * i;
+                pc[i] = reinterpret_cast<cf4>(a.ws.cosb + (size_t)(r0 + (idx >> 4)) * K_BASIS)[idx & 15];
+            }
+        };
+        auto stage = [&](char *buf) __attribute__((always_inline)) {
+            char *PD = buf, *CS = buf + 3 * BW3_P;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = ht_tid + 256 * i;
+                const float x[4] = {pd[i].x, pd[i].y, pd[i].z, pd[i].w};
+                qb2_store4(PD, BW3_P, (idx >> 5) * BW3_PROW + 8 * (idx & 31), x);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = ht_tid + 256 * i;
+                const float x[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
+                qb2_store4(CS, BW3_C, (idx >> 4) * BW3_CROW + 8 * (idx & 15), x);
+            }
+        };
+        float cacc[BWD_CONV_TAPS], cbias = 0.f;
+#pragma unroll
+        for (int i = 0; i < BWD_CONV_TAPS; ++i) cacc[i] = 0.f;
+        // taps of block `blk` (its two tiles) from the masked d e values the partner wave parked
+#define BW3_TAPS(blk_)                                                                                              \
+    do {                                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                             \
+            const int bsm = (row0 + (blk_) * BW3_RB + 16 * t + 4 * g) / T;                                          \
+            const float dcv = s_dcv[((((blk_) & 1) * 4 + wq) * 2 + t) * 64 + lane];                                 \
+            if (sub == 0) cbias += dcv;                                                                             \
+            const float *src = s_obs + (bsm - ws_lo) * 40 * C + ((li >> 3) * 10 + (li & 7)) * C + sub * cpl;        \
+            if (cpl == 2) {                                                                                         \
+                float2 ob[9];                                                                                       \
+                _Pragma("unroll") for (int i = 0; i < 9; ++i)                                                       \
+                    ob[i] = *reinterpret_cast<const float2 *>(src + ((i / 3) * 10 + (i % 3)) * C);                  \
+                _Pragma("unroll") for (int i = 0; i < 9; ++i) {                                                     \
+                    cacc[i] = fmaf(dcv, ob[i].x, cacc[i]);                                                          \
+                    cacc[9 + i] = fmaf(dcv, ob[i].y, cacc[9 + i]);                                                  \
+                }                                                                                                   \
+            } else {                                                                                                \
+                float ob[9];                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 9; ++i) ob[i] = src[((i / 3) * 10 + (i % 3)) * C];            \
+                _Pragma("unroll") for (int i = 0; i < 9; ++i) cacc[i] = fmaf(dcv, ob[i], cacc[i]);                  \
+            }                                                                                                       \
+        }                                                                                                           \
+    } while (0)
+        request(0);
+        // (the observation rows behind the first block's operands: memory operations of a wave return in order)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = lane + 64 * i;
+            if (idx < ws_n * 10 * C) {
+                const int sm = idx / (10 * C), o4 = idx - sm * 10 * C;
+                const float *src = a.obs + ((int64_t)(ws_lo + sm) * 100 + y0 * 10) * C + 4 * o4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(s_obs + 256 * i), 16, 0, 0);
+            }
+        }
+        stage(smem);
+        lds_barrier();                                              // (1) block 0 is parked
+        for (int blk = 0; blk < nblk; ++blk) {
+            if (n_mine && blk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's observation rows have landed
+            if (blk + 1 < nblk) request(blk + 1);
+            if (n_mine && blk >= 1) BW3_TAPS(blk - 1);
+            if (blk + 1 < nblk) stage(smem + ((blk + 1) & 1) * BW3_BUF);
+            lds_barrier();                                          // (2 + blk)
+        }
+        if (n_mine) {
+            if (nblk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BW3_TAPS(nblk - 1);
+#undef BW3_TAPS
+            // fold the 16 positions of a lane group, park one row per (wave, lane group), then the wave's own outputs
+            constexpr int TS = BWD_CONV_TAPS + 1;
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                float v = i < BWD_CONV_TAPS ? cacc[i < BWD_CONV_TAPS ? i : 0] : cbias;
+                v += dpp_move<0xB1, 0xF>(0.f, v);
+                v += dpp_move<0x4E, 0xF>(0.f, v);
+                v += dpp_move<0x124, 0xF>(0.f, v);
+                v += dpp_move<0x128, 0xF>(0.f, v);
+                if (li == 0) s_tap[(wq * 4 + g) * TS + i] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= 9 * C) {
+                // output tap o belongs to lane subset so = o / n_mine; for T = 8 lane groups so and so + 2 hold it
+                const int so = lane < 9 * C ? lane / n_mine : 0, i = lane < 9 * C ? lane - so * n_mine : BWD_CONV_TAPS;
+                float tsum = s_tap[(wq * 4 + so) * TS + i];
+                if (T == 8) tsum += s_tap[(wq * 4 + so + 2) * TS + i];
+                a.ws.convpart[(int64_t)(rc * (E_DIM / 16) + cs) * BWD_CONV_ROW + lane] = tsum;
+            }
+        }
+        PRISM_STAMP(26);
+        return;
+    }
+    // =============================== computing waves ===============================
+    const bool want_dcv = a.conv_in_bwd != 0;
+    // the W1 slice of the wave's columns as the B operand of dX (K = hidden unit), split once
     Split3 w1p[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -82,37 +214,6 @@ __global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
 #pragma unroll
     for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f, s_dbphi = 0.f, de_acc = 0.f;
-
-    // ---- staging: 32 rows of dpre1 (4 float4 a thread) and of the cos basis (2), requested one block ahead
-    float4 pd[4], pc[2];
-    auto request = [&](int blk) __attribute__((always_inline)) {
-        const int r0 = row0 + blk * BW3_RB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            pd[i] = reinterpret_cast<cf4>(a.ws.dpre1 + (size_t)(r0 + (idx >> 5)) * H)[idx & 31];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            pc[i] = reinterpret_cast<cf4>(a.ws.cosb + (size_t)(r0 + (idx >> 4)) * K_BASIS)[idx & 15];
-        }
-    };
-    auto stage = [&](char *buf) __attribute__((always_inline)) {
-        char *PD = buf, *CS = buf + 3 * BW3_P;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const float x[4] = {pd[i].x, pd[i].y, pd[i].z, pd[i].w};
-            qb2_store4(PD, BW3_P, (idx >> 5) * BW3_PROW + 8 * (idx & 31), x);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const float x[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
-            qb2_store4(CS, BW3_C, (idx >> 4) * BW3_CROW + 8 * (idx & 15), x);
-        }
-    };
     // per-wave row data of a block: saved ReLU(phi) of the wave's columns, LayerNorm row scalars, the samples' embeddings
     struct RowData {
         f32x4 ph[2], mu[2], rs[2], c1[2], c2[2];
@@ -135,24 +236,18 @@ __global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
         }
     };
     RowData D;
-    request(0);
     load_rows(D, 0);
-    stage(smem);
-    lds_barrier();
+    lds_barrier();                                                  // (1)
     PRISM_STAMP(9);
     for (int blk = 0; blk < nblk; ++blk) {
         const char *cur = smem + (blk & 1) * BW3_BUF;
-        char *nxt = smem + ((blk + 1) & 1) * BW3_BUF;
         const bool more = blk + 1 < nblk;
-        if (more) request(blk + 1);
         const char *PD = cur, *CS = cur + 3 * BW3_P;
         float xs8[8], dp8[8];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int r0 = row0 + blk * BW3_RB + 16 * t;
             // dX[m = 4g + r][n] = sum_h dpre1[m][h] W1[h][n]: A = the image's rows (eight consecutive hidden units a lane)
-            // (all operand reads of a phase are issued before its first MFMA: one LDS round trip a phase, not one a group --
-            // the wave is alone on its SIMD, there are registers to spare)
             f32x4 adx = {0.f, 0.f, 0.f, 0.f};
             u32x4 xa[4][3];
 #pragma unroll
@@ -183,20 +278,25 @@ __global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
             }
             // d e[b][n]: sum over the T rows of a sample
             const int bsm = (r0 + 4 * g) / T;
+            const bool ev_pos = ev > 0.f;
+            float dcv = 0.f;          // ReLU-masked d e of (sample, column n) when it is final in this lane
             if (T == 4) {
                 a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
             } else if (T == 8) {
                 dep += __shfl_xor(dep, 16, 64);
-                if ((g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+                if (!want_dcv && (g & 1) == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = dep;
+                dcv = ev_pos ? dep : 0.f;
             } else {
                 dep += __shfl_xor(dep, 16, 64);
                 dep += __shfl_xor(dep, 32, 64);
                 de_acc += dep;
                 if (((r0 + 16) % T) == 0) {
-                    if (g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
+                    if (!want_dcv && g == 0) a.ws.de_iqn[(int64_t)bsm * E_DIM + n] = de_acc;
+                    dcv = ev_pos ? de_acc : 0.f;
                     de_acc = 0.f;
                 }
             }
+            if (want_dcv) s_dcv[(((blk & 1) * 4 + wq) * 2 + t) * 64 + lane] = dcv;      // (the helper wave reads it behind the barrier)
         }
         if (more) load_rows(D, blk + 1);          // (this block's row data is consumed)
         const Split3 X = split_bf16x3(xs8), DP = split_bf16x3(dp8);
@@ -218,8 +318,7 @@ __global__ __launch_bounds__(256) void iqn_bwd3_kernel(IqnArgs a) {
         // dW1[h][n] += sum_m dpre1[m][h] x[m][n]: A = dpre1 by transposed reads of the same image, B = x (own registers)
 #pragma unroll
         for (int ht = 0; ht < NHT; ++ht) accW1[ht] = mfma_split(wa[ht][0], wa[ht][1], wa[ht][2], X, accW1[ht]);
-        if (more) stage(nxt);
-        lds_barrier();
+        lds_barrier();                                              // (2 + blk)
     }
     PRISM_STAMP(10);
     // ---- this wave's part of the chunk's slab: nobody else holds these columns

@@ -118,8 +118,7 @@ static int use_split(const prism_learner_desc *ld) {
 static bool use_bw3(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     static const bool off = [] { const char *e = getenv("PRISM_NO_BWD3"); return e && atoi(e) != 0; }();
-    // (models with Q heads only: IQN-only models carry their conv-backward taps in iqn_bwd_kernel, bwd3_kernels.h)
-    return !off && d.use_iqn && d.n_heads > 0 && use_split(ld) && bw3_ok(d.iqn_width, ld->batch, d.n_tau, true);
+    return !off && d.use_iqn && use_split(ld) && bw3_ok(d.iqn_width, ld->batch, d.n_tau, true);
 }
 
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
@@ -286,7 +285,7 @@ static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 
 
 static bool conv_in_bwd(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
-    if (use_bw3(ld)) return false;
+    if (use_bw3(ld)) return bw3_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch);
     return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, bwd_chunks(iqn_width(d)),
                        iqn_width(d));
 }
@@ -295,7 +294,8 @@ static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(d.in_channels);
     return post_blocks(ld->batch, d.use_iqn, d.n_heads, conv_in_bwd(ld), iqn_slab_floats(iqn_width(d), d.use_layer_norm),
-                       q_slab_floats(head_width(d), d.use_layer_norm), iqn_width(d), head_width(d));
+                       q_slab_floats(head_width(d), d.use_layer_norm), iqn_width(d), head_width(d),
+                       use_bw3(ld) ? BW3_RC : bwd_chunks(iqn_width(d)));
 }
 
 static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
@@ -646,13 +646,13 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
     if (ld->dims.use_iqn && use_bw3(ld)) {
         ProfileScope ps_(K_BWD, stream);
         const dim3 grid((E_DIM / 64) * BW3_RC);
-        const size_t lds = BW3_LDS_BYTES;
+        const size_t lds = (size_t)bw3_lds_bytes(B, a.T, a.C, a.conv_in_bwd != 0);
         if (a.ln) {
-            herr = set_max_lds((const void *)iqn_bwd3_kernel<true>, lds);
-            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<true>), grid, dim3(256), lds, stream, a);
+            herr = set_max_lds((const void *)iqn_bwd3_kernel<true>, 160 * 1024);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<true>), grid, dim3(512), lds, stream, a);
         } else {
-            herr = set_max_lds((const void *)iqn_bwd3_kernel<false>, lds);
-            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<false>), grid, dim3(256), lds, stream, a);
+            herr = set_max_lds((const void *)iqn_bwd3_kernel<false>, 160 * 1024);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd3_kernel<false>), grid, dim3(512), lds, stream, a);
         }
         if (herr != hipSuccess) {
             set_error("hipFuncSetAttribute(iqn_bwd3): %s", hipGetErrorString(herr));

@@ -295,13 +295,14 @@ __global__ __launch_bounds__(NT) void step_front_kernel(IqnArgs a, prism_replay_
 //   [.., + POST_SMALL_BLOCKS)             small tensors (b1, LN2, W2, b2) by 64-wide slices of H, + total loss
 // Every block leaves its sum of squares in normpart[blockIdx.x].
 // ------------------------------------------------------------------------------------------
-__host__ __device__ inline int post_slab_blocks(int slab) { return (slab / 4 + 1023) / 1024; }
+// one thread per float4 of the slab; two (adjacent lanes, eight chunks each) when the backward wrote sixteen row chunks
+__host__ __device__ inline int post_slab_blocks(int slab, int n_chunks = 8) { return ((slab / 4) * (n_chunks > 8 ? 2 : 1) + 1023) / 1024; }
 __host__ __device__ inline int post_small_blocks(int H) { return H / SMALL_W; }     // 16 hidden units per block
 __host__ __device__ inline int post_q_slab_blocks(int n_heads, int q_slab) { return (n_heads * (q_slab / 4) + 1023) / 1024; }
 __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd, int slab, int q_slab, int Hi,
-                                           int Hq) {
+                                           int Hq, int n_chunks = 8) {
     int n = conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
-    if (use_iqn) n += post_slab_blocks(slab) + post_small_blocks(Hi);
+    if (use_iqn) n += post_slab_blocks(slab, n_chunks) + post_small_blocks(Hi);
     if (n_heads) n += post_q_slab_blocks(n_heads, q_slab) + n_heads * post_small_blocks(Hq);
     return n;
 }
@@ -758,23 +759,36 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         blk -= n_conv;
         bool done = false;
         if (a.use_iqn) {
-            const int n_slab = post_slab_blocks(a.slab), n_small = post_small_blocks(a.Hi);
+            const int n_slab = post_slab_blocks(a.slab, a.n_chunks), n_small = post_small_blocks(a.Hi);
             if (blk < n_slab) {
-                const int i = blk * 1024 + tid;
+                // sixteen row chunks (the 64-column backward): a float4 is summed by TWO adjacent lanes, eight chunks each
+                // ((c0 + .. + c7) + (c8 + .. + c15), the same in both lanes); the even lane owns the result
+                const bool two = a.n_chunks > 8;
+                const int t = blk * 1024 + tid, i = two ? t >> 1 : t, half = two ? (t & 1) : 0;
                 PRISM_STAMP(8);
-                if (i < a.slab / 4) {
-                    // every chunk's partial requested before the first add (sixteen chunks from the 64-column backward,
-                    // eight or four from the 16-column one), then summed in chunk order
-                    float4 s = reinterpret_cast<const float4 *>(a.ws.slabs)[i];
-                    float4 v[15];
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool in = i < a.slab / 4;
+                if (in) {
+                    // every chunk's partial requested before the first add, then summed in chunk order
+                    const int c0 = 8 * half, nc = two ? 8 : a.n_chunks;
+                    s = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c0 * a.slab)[i];
+                    float4 v[7];
 #pragma unroll
-                    for (int c = 1; c < 16; ++c)
-                        if (c < a.n_chunks) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)c * a.slab)[i];
+                    for (int c = 1; c < 8; ++c)
+                        if (c < nc) v[c - 1] = reinterpret_cast<const float4 *>(a.ws.slabs + (int64_t)(c0 + c) * a.slab)[i];
 #pragma unroll
-                    for (int c = 1; c < 16; ++c)
-                        if (c < a.n_chunks) {
+                    for (int c = 1; c < 8; ++c)
+                        if (c < nc) {
                             s.x += v[c - 1].x; s.y += v[c - 1].y; s.z += v[c - 1].z; s.w += v[c - 1].w;
                         }
+                }
+                if (two) {
+                    s.x += __shfl_xor(s.x, 1, 64);
+                    s.y += __shfl_xor(s.y, 1, 64);
+                    s.z += __shfl_xor(s.z, 1, 64);
+                    s.w += __shfl_xor(s.w, 1, 64);
+                }
+                if (in && half == 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PRISM_STAMP(7);
                     stream_store4(reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i), s);
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     PRISM_STAMP(14);
     if constexpr (TAIL) {
         const int n_role = wb.enabled ? (int)gridDim.x - 1 : (int)gridDim.x;
-        const int n_slab = a.use_iqn ? post_slab_blocks(a.slab) : 0;
+        const int n_slab = a.use_iqn ? post_slab_blocks(a.slab, a.n_chunks) : 0;
         const int sb = (int)blockIdx.x - n_conv;
         TailShare sh;
         sh.nleft = (tl.adam.n >> 2) - (a.use_iqn ? a.slab >> 2 : 0);
@@ -859,8 +873,10 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         sh.cnt = a.use_iqn ? a.slab >> 2 : 0;
         sh.g = g_own;
         if (a.use_iqn && sb >= 0 && sb < n_slab) {
-            sh.own = sh.have = (int64_t)sb * 1024 + tid < sh.cnt;
-            sh.j = sh.s0 + (int64_t)sb * 1024 + tid;
+            const bool two = a.n_chunks > 8;
+            const int64_t t = (int64_t)sb * 1024 + tid, i = two ? t >> 1 : t;
+            sh.own = sh.have = i < sh.cnt && (!two || (t & 1) == 0);
+            sh.j = sh.s0 + i;
             sh.k = sh.kstride = 0;
             sh.scalar_tail = false;
         } else {
