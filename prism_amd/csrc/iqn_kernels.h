@@ -254,48 +254,95 @@ __device__ __forceinline__ void iqn_uv_block(const IqnArgs &a, int set, int h, i
     }
 }
 
-// Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS.
-// `s_w`: the 3x3 taps of every (out channel, in channel) pair padded to CONV_W_PAD floats, 16-byte aligned
-// (conv_w_slot maps a flat weight index to its LDS slot): three 16-byte reads per pair instead of nine.
-constexpr int CONV_W_PAD = 12;
-__device__ __forceinline__ int conv_w_slot(int i) { return (i / 9) * CONV_W_PAD + i % 9; }
-// NW waves take part (4 or 8): wave w0 = the output channels w0, w0 + NW, ...; `tid` counts from the first of them.
-template <int NW = 4>
-__device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
-                                                float *__restrict__ dst, int tid, int nthreads) {
-    // thread = output position (y, x) x a group of 16 / NW output channels c0, c0 + NW, ...:
-    // the 3x3 input patch of a channel is read once and feeds all of them (their weight reads are
-    // wave-uniform broadcasts).  Per output the fmaf chain runs (ci, dy, dx)-major from zero and the bias is added to the
-    // finished sum (accumulating ONTO a large bias rounds at the bias's magnitude 9 C times: tests/test_gpu_ln_stress.py).
-    constexpr int NCH = 16 / NW;
-    const int c0 = tid >> 6, y = (tid >> 3) & 7, x = tid & 7;
-    float acc[NCH];
+// Conv2d(C->16, 3x3) + ReLU + channel-major flatten of one NHWC observation held in LDS, on the matrix core:
+// out[16 channels][64 positions] = W[16][K] x patches[K][64], K = 9 C, as 16x16x4 fp32 MFMAs -- four waves, one 16-position
+// tile each, K / 4 MFMAs per wave.  (As fmaf chains, one output position x four channels a thread, the convolution of one
+// observation took 2.0-3.4 k cycles and was the largest single piece of the front launch; the MFMA form reads 2 x K / 4
+// words per lane and issues K / 4 matrix instructions: ~0.5 k.)  K runs (ci, dy, dx)-major like the stored weights, so
+// W[m][k] = conv_w[m * 9 C + k]; the bias is added to the finished sum.
+//   s_obs   CHANNEL-major image of the observation, s_obs[ci * 100 + y * 10 + x] (obs_to_lds: the stored order is
+//           position-major with C interleaved channels, which puts a wave's reads on 8 of the 32 banks)
+//   s_w     [16][conv_kp(C)]: the weights of an output channel, zero-padded to a multiple of four
+__host__ __device__ constexpr int conv_kp(int C) { return (9 * C + 3) & ~3; }
+constexpr int CONV_W_FLOATS = 16 * conv_kp(10);
+__device__ __forceinline__ int conv_w_slot(int i, int C) { return i + (i / (9 * C)) * (conv_kp(C) - 9 * C); }
+// every thread of the workgroup: weights + padding + bias of one parameter set into LDS (P = the set's flat parameters)
+__device__ __forceinline__ void conv_w_to_lds(const float *__restrict__ P, const prism_param_offsets &off, int C, float *s_w, float *s_b,
+                                              int tid, int nthreads) {
+    const int KP = conv_kp(C), K = 9 * C;
+    for (int i = tid; i < 16 * KP; i += nthreads) {
+        const int m = i / KP, k = i - m * KP;
+        s_w[i] = k < K ? P[off.conv_w + m * K + k] : 0.f;
+    }
+    if (tid < 16) s_b[tid] = P[off.conv_b + tid];
+}
+// obs_to_lds(): the four consecutive stored elements 4 t .. 4 t + 3 to their places.
+__device__ __forceinline__ void obs_to_lds(float *s_obs, const float4 v, int t, int C) {
+    const unsigned int m = 65536u / (unsigned int)C + 1u;             // e / C == (e * m) >> 16 for e < 1000, C <= 10
+    const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
-    for (int ci = 0; ci < C; ++ci) {
-        float p[9];
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int e = 4u * (unsigned int)t + j, pos = (e * m) >> 16, ci = e - pos * (unsigned int)C;
+        s_obs[ci * 100u + pos] = x[j];
+    }
+}
+// waves 0..3 of the caller (tid < 256).  Branch-free: all operand words of a run of K steps are requested before the
+// first MFMA (written with a bounds test per step the loop was one LDS round trip per matrix instruction: 2.2 k cycles
+// for nine of them, tools/ubench/conv_embed.hip); a padded step reads a valid word against a zero weight.
+template <int KSTEPS>      // the number of K steps when it is known at compile time (C = 4: nine), else 0
+__device__ __forceinline__ void conv_embed_rows_k(const float *s_obs, const float *s_w, const float *s_b, int C,
+                                                  float *__restrict__ dst, int tid) {
+    const int lane = tid & 63, j = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int KP = KSTEPS ? 4 * KSTEPS : conv_kp(C), K = 9 * C;
+    const int y = 2 * j + (n >> 3), x = n & 7;
+    const float *wrow = s_w + n * KP + kq;                 // A operand: lane supplies W[m = lane & 15][k = 4 s + kq]
+    const float *orow = s_obs + y * 10 + x;                // B operand: patch element k of position 16 j + n
+    auto patch = [&](int s4) {
+        int k = s4 + kq;
+        k = k < K ? k : K - 1;
+        const int ci = (k * 7282) >> 16;                   // k / 9 for k < 1000
+        const int t = k - 9 * ci, dy = (t * 11) >> 5;      // t / 3 for t < 9
+        return orow[ci * 100 + dy * 10 + (t - 3 * dy)];
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (KSTEPS > 0) {
+        float av[KSTEPS], bv[KSTEPS];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) p[t] = s_obs[((y + t / 3) * 10 + (x + t % 3)) * C + ci];
+        for (int s = 0; s < KSTEPS; ++s) {
+            av[s] = wrow[4 * s];
+            bv[s] = patch(4 * s);
+        }
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const float4 *w4 = reinterpret_cast<const float4 *>(s_w + ((c0 + NW * k) * C + ci) * CONV_W_PAD);
-            const float4 wa = w4[0], wb = w4[1], wc = w4[2];
-            const float w[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
+        for (int s = 0; s < KSTEPS; ++s) acc = mfma16(av[s], bv[s], acc);
+    } else {
+        for (int s4 = 0; s4 < KP; s4 += 12) {              // runs of three steps (KP = 4 (9 C + 3) / 4; at most one run reads past it)
+            float av[3], bv[3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[k] = fmaf(w[t], p[t], acc[k]);
+            for (int u = 0; u < 3; ++u) {
+                const int q = s4 + 4 * u < KP ? s4 + 4 * u : KP - 4;
+                av[u] = s4 + 4 * u < KP ? wrow[q] : 0.f;
+                bv[u] = patch(q);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) acc = mfma16(av[u], bv[u], acc);
         }
     }
+    // D: lane holds channels 4 kq + r at position 16 j + n
 #pragma unroll
-    for (int k = 0; k < NCH; ++k)
-        __builtin_nontemporal_store(fmaxf(acc[k] + s_b[c0 + NW * k], 0.f), &dst[(c0 + NW * k) * 64 + (tid & 63)]);
-    (void)nthreads;
+    for (int r = 0; r < 4; ++r)
+        __builtin_nontemporal_store(fmaxf(acc[r] + s_b[4 * kq + r], 0.f), &dst[(4 * kq + r) * 64 + 16 * j + n]);
+}
+__device__ __forceinline__ void conv_embed_rows(const float *s_obs, const float *s_w, const float *s_b, int C,
+                                                float *__restrict__ dst, int tid) {
+    if (C == 4) conv_embed_rows_k<9>(s_obs, s_w, s_b, C, dst, tid);
+    else conv_embed_rows_k<0>(s_obs, s_w, s_b, C, dst, tid);
 }
 
 __device__ void embed_extra_block(const IqnArgs &a, int x, float *s_red);
 
 __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
-    __shared__ float s_obs[1024];
-    __shared__ __attribute__((aligned(16))) float s_w[16 * 10 * CONV_W_PAD];
+    __shared__ __attribute__((aligned(16))) float s_obs[1024];
+    __shared__ __attribute__((aligned(16))) float s_w[CONV_W_FLOATS];
     __shared__ float s_b[16];
     const int B = a.B, C = a.C;
     const int blk = blockIdx.x, tid = threadIdx.x;
@@ -308,13 +355,10 @@ __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
     const float *P = (is_next && a.has_target) ? a.target_params : a.params;
     const float *src = (is_next ? a.next_obs : a.obs) + (int64_t)b * 100 * C;
     float *dst = (is_next ? a.ws.e_next : a.ws.e_cur) + (int64_t)b * E_DIM;
-#pragma unroll 4
-    for (int i = tid; i < 100 * C; i += 256) s_obs[i] = src[i];
-#pragma unroll 4
-    for (int i = tid; i < 16 * C * 9; i += 256) s_w[conv_w_slot(i)] = P[a.off.conv_w + i];
-    if (tid < 16) s_b[tid] = P[a.off.conv_b + tid];
+    if (tid < 25 * C) obs_to_lds(s_obs, reinterpret_cast<const float4 *>(src)[tid], tid, C);
+    conv_w_to_lds(P, a.off, C, s_w, s_b, tid, 256);
     __syncthreads();
-    conv_embed_rows(s_obs, s_w, s_b, C, dst, tid, 256);
+    conv_embed_rows(s_obs, s_w, s_b, C, dst, tid);
 }
 
 // Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight
@@ -327,6 +371,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
     do {                                                                                   \
         if ((a.dbg & 16) && threadIdx.x == 0 && blockIdx.x >= 256)                         \
             a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#define PRISM_STAMP2(k)                                                                    \
+    do {                                                                                   \
+        if ((a.dbg & 8) && threadIdx.x == 0)                                               \
+            a.stamps[(size_t)(2048 + blockIdx.x) * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define PRISM_STAMP(k)                                                                     \
     do {                                                                                   \

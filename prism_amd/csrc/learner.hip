@@ -928,10 +928,7 @@ extern "C" int prism_step_front(const prism_learner_desc *ld, const prism_replay
     {
         ProfileScope ps_(K_FRONT, stream);
         const int extra = front_extra_blocks(extra_dims(a));
-        if (front_threads(ld->batch, extra) == 512)
-            hipLaunchKernelGGL(step_front_kernel<512>, dim3(ld->batch + extra), dim3(512), 0, stream, a, *rp, f);
-        else
-            hipLaunchKernelGGL(step_front_kernel<256>, dim3(ld->batch + extra), dim3(256), 0, stream, a, *rp, f);
+        hipLaunchKernelGGL(step_front_kernel, dim3(ld->batch + extra), dim3(256), 0, stream, a, *rp, f);
         PRISM_CHECK_LAUNCH();
     }
     return PRISM_OK;

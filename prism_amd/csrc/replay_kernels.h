@@ -121,6 +121,41 @@ __device__ __forceinline__ float2 tree_query_fold(const float *scratch, int64_t 
     return make_float2(s, m);
 }
 
+// tree_query_fetch for ONE WAVE, lane = level, in closed form.  With l = cap = 2^L the walk's left end stays a power of two
+// (l_i = cap >> i, never odd below the root), so only right ends contribute: level i adds node (r >> i) - 1 when r >> i is
+// odd and still right of l_i -- the binary decomposition of [0, r_in).  Same nodes, and lane order = slot order.
+__device__ __forceinline__ float2 tree_query_fetch_wave(const float2 *__restrict__ v, int64_t cap, int64_t tree_size,
+                                                        int64_t r_in) {
+    float2 val = make_float2(0.0f, FLT_MAX);
+    const int level = threadIdx.x & 63;
+    if (r_in >= tree_size) return level == 0 ? v[1] : val;          // whole tree: 0 + root, min(FLT_MAX, root)
+    const int L = 63 - __clzll((unsigned long long)cap);
+    const int64_t r = (r_in | cap) >> level, l = cap >> level;
+    if (level < L && (r & 1) && l < r) val = v[r - 1];
+    return val;
+}
+
+// The fold for ONE WAVE whose lane t holds slot t of tree_query_fetch (levels < 32): the sum walks the slots that hold
+// something in slot order (an identity slot adds +0.0f, an exact no-op, so skipping it changes nothing), the minimum is
+// order-free and takes the DPP reduction.
+__device__ __forceinline__ float2 tree_query_fold_wave(const float2 val) {
+    unsigned long long live = __ballot(val.x != 0.0f);
+    float s = 0.0f;
+    while (live) {
+        const int i = __builtin_ctzll(live);
+        live &= live - 1;
+        s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val.x), i));
+    }
+    float m = val.y, o;
+    o = dpp_move<0xB1, 0xF>(m, m); m = o < m ? o : m;
+    o = dpp_move<0x4E, 0xF>(m, m); m = o < m ? o : m;
+    o = dpp_move<0x124, 0xF>(m, m); m = o < m ? o : m;
+    o = dpp_move<0x128, 0xF>(m, m); m = o < m ? o : m;
+    o = dpp_move<0x142, 0xA>(m, m); m = o < m ? o : m;
+    o = dpp_move<0x143, 0xC>(m, m); m = o < m ? o : m;
+    return make_float2(s, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63)));
+}
+
 static __global__ void replay_init_kernel(prism_replay_desc rp) {
     const int64_t n = 2 * rp.tree_capacity;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -751,6 +786,91 @@ __device__ __forceinline__ int64_t tree_descend_record(const prism_replay_desc &
         if (three) step(sel(r1, sel(r2, c0, c1), sel(r2, c2, c3)));
     }
     return node ^ cap;
+}
+
+// The descent as ONE WAVE with one sample (the fused front launch): every lane runs it with the same mass.  The node
+// pairs {left.sum, left.min, right.sum, right.min} = t4[parent] live in registers, spread over the lanes, and the walk
+// picks them up with v_readlane at a wave-uniform lane number -- no LDS, no per-level memory round trip.
+// A dependent round trip to the tree costs ~1.8 k cycles here (the L2s are invalidated at every kernel boundary), a level
+// out of registers ~100.  `top[j]` = t4[lane + 64 j], j < 2: the SEVEN levels under the root, fetched by the caller together
+// with its other first-round loads; below them a trip fetches the up to SIX levels under the current node, one load per
+// lane: pair number i = lane (1 <= i < 64) is the node's descendant i - 2^k at depth k = floor(log2 i).  17 levels: two
+// dependent trips (the one-lane form made four of three levels each).  Measured and not kept: nine levels up front and
+// eight per trip (one dependent trip for 17 levels) -- the 64 cold lines of the nine-level top cost the first round of
+// loads 2.4 k cycles more than the trip saved.
+// Same arithmetic, same order as tree_descend_record.  The sibling {sum, min} of level s (0 = leaf level) is left in
+// lane s of `sib`.
+struct WaveDescent {
+    int64_t idx;
+    float leaf_sum;
+    float2 sib;
+};
+__device__ __forceinline__ float4 readlane4(const float4 &v, int lane) {
+    return make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), lane)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), lane)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), lane)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.w), lane)));
+}
+__device__ __forceinline__ float4 pick4(bool hi, const float4 &x, const float4 &y) {
+    return make_float4(hi ? y.x : x.x, hi ? y.y : x.y, hi ? y.z : x.z, hi ? y.w : x.w);
+}
+constexpr int WAVE_TOP_REGS = 2, WAVE_TOP_LEVELS = 7, WAVE_TRIP_LEVELS = 6;
+__device__ __forceinline__ void wave_top_fetch(const prism_replay_desc &rp, float4 (&top)[WAVE_TOP_REGS]) {
+    const float4 *t4 = reinterpret_cast<const float4 *>(rp.tree);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < WAVE_TOP_REGS; ++j) {
+        top[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane + 64 * j < rp.tree_capacity) top[j] = t4[lane + 64 * j];
+    }
+}
+__device__ __forceinline__ WaveDescent tree_descend_wave(const prism_replay_desc &rp, const float4 (&top)[WAVE_TOP_REGS],
+                                                         float mass) {
+    const int lane = threadIdx.x & 63;
+    const int cap = (int)rp.tree_capacity;            // <= 2^24
+    WaveDescent r;
+    r.sib = make_float2(0.f, 0.f);
+    r.leaf_sum = 0.f;
+    const float root = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(top[0].z), 0));      // node 1 = second half of t4[0]
+    if (mass > root) {
+        r.idx = rp.capacity;
+        return r;
+    }
+    const int L = 31 - __clz(cap);
+    // everything but `v` is kept scalar: the comparison's lane mask (all lanes agree) selects between readlane results in
+    // SGPRs
+    int node = 1, s = L, sibx = 0, siby = 0;
+    float v = mass, leaf = 0.f;
+    auto step = [&](const float4 ch) {
+        --s;
+        const bool right = __ballot(v > ch.x) != 0ull;
+        v = right ? v - ch.x : v;
+        node = 2 * node + (right ? 1 : 0);
+        const float sx = right ? ch.x : ch.z, sy = right ? ch.y : ch.w;
+        sibx = lane == s ? __float_as_int(sx) : sibx;
+        siby = lane == s ? __float_as_int(sy) : siby;
+        leaf = right ? ch.z : ch.x;
+    };
+    if (L >= WAVE_TOP_LEVELS) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) step(readlane4(top[0], node));       // node in [2^k, 2^(k+1))
+        step(readlane4(top[1], node - 64));
+    } else {
+        for (int k = 0; k < L; ++k) step(readlane4(node < 64 ? top[0] : top[1], node & 63));
+    }
+    const float4 *t4 = reinterpret_cast<const float4 *>(rp.tree);
+    const int kd = 31 - __clz(lane | 1);
+    while (s > 0) {
+        const int nl = s < WAVE_TRIP_LEVELS ? s : WAVE_TRIP_LEVELS;       // s = levels still to go
+        float4 sub = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane >= 1 && lane < (1 << nl)) sub = t4[(node << kd) + (lane - (1 << kd))];
+        const int base = node;
+        for (int j = 1; j <= nl; ++j) step(readlane4(sub, node - (base << (j - 1)) + (1 << (j - 1))));
+    }
+    r.idx = node ^ cap;
+    r.sib = make_float2(__int_as_float(sibx), __int_as_float(siby));
+    r.leaf_sum = leaf;
+    return r;
 }
 
 // _compute_n_step (timestep_buffer.py:198-238) over the slot arrays; wave-uniform

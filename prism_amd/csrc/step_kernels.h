@@ -108,31 +108,23 @@ struct FrontArgs {
 // blocks [0, B): one sample each — tree descent, n-step walk, row gather, conv3x3+ReLU of both
 // observations;  blocks [B, B + H/4): u = W1 g1, v = W1 beta1;  then PACK_BLOCKS (x2 with a target
 // network) blocks refresh the fragment-packed weight copies tile_fwd streams.
-// 512 threads: waves 0-3 as before (wave 0 samples, waves 1-3 stage the conv weights); waves 4-7 convolve the CURRENT
-// observation while lane 0 of wave 0 walks the n-step links (three dependent loads), and all eight waves convolve the
-// successor once its row has arrived.  Sequential form (256 threads): walk 3.8 k + both convolutions 7.5 k cycles behind
-// the sampled index; now walk ‖ first convolution, then the second at two output channels a wave.
-// NT = 256 is the sequential form, kept for the configurations whose launch is mostly parameter-only blocks (ten Q heads
-// and a target network: ~1500 packing blocks beside 512 sample blocks -- half-empty 512-thread workgroups cost that launch
-// 5 us): the host picks by block counts (front_threads).
-__host__ __device__ inline int front_threads(int B, int extra_blocks) { return extra_blocks <= B ? 512 : 256; }
-template <int NT>
-__global__ __launch_bounds__(NT) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
+// 256 threads: wave 0 samples, waves 1-3 stage the conv weights; the convolutions run on the matrix core, one 16-position
+// tile per wave (conv_embed_rows).  (An eight-wave form that convolved with fmaf chains beside the n-step walk was the
+// round-3 intermediate: the MFMA convolution is shorter on four waves than that one was on eight.)
+__global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay_desc rp, FrontArgs f) {
     kernarg_prefetch<sizeof(IqnArgs) + sizeof(prism_replay_desc) + sizeof(FrontArgs)>();
-    __shared__ __attribute__((aligned(16))) float2 s_top[TOP_NODES];
     __shared__ __attribute__((aligned(16))) float s_scratch[256];
-    __shared__ float s_obs[2][1000];
-    __shared__ __attribute__((aligned(16))) float s_w[2][16 * 10 * CONV_W_PAD];
+    __shared__ __attribute__((aligned(16))) float s_obs[2][1000];
+    __shared__ __attribute__((aligned(16))) float s_w[2][CONV_W_FLOATS];
     __shared__ float s_b[2][16];
     __shared__ int64_t s_i64[2];
     __shared__ float2 s_sibrec[TREE_MAX_LEVELS];
     __shared__ float s_out_w;
-    __shared__ unsigned int s_rec_state;
+    __shared__ unsigned int s_rec_state, s_rec_state2;
     __shared__ uint32_t s_flags;
     const int B = a.B, C = a.C, tid = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= B) {
-        if (NT > 256 && tid >= 256) return;      // (the parameter-only roles are 256-thread routines)
         PRISM_STAMP(27);
         front_extra_block(a, b - B, s_scratch);
         PRISM_STAMP(31);
@@ -140,99 +132,67 @@ __global__ __launch_bounds__(NT) void step_front_kernel(IqnArgs a, prism_replay_
     }
     PRISM_STAMP(27);
     // Everything that does not depend on the sampled index is requested in ONE round of loads.  Wave 0 is the sampler:
-    // its lanes fetch the tree top and the nodes of the p_sum / p_min query, park them in LDS and go on alone (a wave
-    // sees its own LDS writes without a workgroup barrier); waves 1-3 fetch the conv weights of both networks meanwhile
-    // -- those are not needed before the rows are convolved, two barriers further down.
+    // its lanes fetch the tree top and the nodes of the p_sum / p_min query and go on alone, everything in registers;
+    // waves 1-3 stage the conv weights of both networks meanwhile -- those are not needed before the rows are convolved.
     const float *P0 = a.params, *P1 = a.has_target ? a.target_params : a.params;
-    const int nw = 16 * C * 9;
     const int64_t cap = rp.tree_capacity;
-    const int64_t top = cap < TOP_NODES ? cap : TOP_NODES;
-    constexpr int TOP_PER_LANE = (TOP_NODES + 63) / 64, W_PER_THREAD = 8;       // 16 * 10 * 9 = 1440 weights <= 8 * 192
     int64_t idx;
-    if (NT > 256 && tid >= 256) {
-        // (waves 4-7: nothing to fetch)
-    } else if (tid >= 64) {
-        const int t = tid - 64;
-        float wr[2][W_PER_THREAD], br[2] = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < W_PER_THREAD; ++k) {
-            const int i = t + 192 * k;
-            wr[0][k] = wr[1][k] = 0.f;
-            if (i < nw) {
-                wr[0][k] = P0[a.off.conv_w + i];
-                wr[1][k] = P1[a.off.conv_w + i];
-            }
-        }
-        if (t < 16) {
-            br[0] = P0[a.off.conv_b + t];
-            br[1] = P1[a.off.conv_b + t];
-        }
-#pragma unroll
-        for (int k = 0; k < W_PER_THREAD; ++k) {
-            const int i = t + 192 * k;
-            if (i < nw) {
-                s_w[0][conv_w_slot(i)] = wr[0][k];
-                s_w[1][conv_w_slot(i)] = wr[1][k];
-            }
-        }
-        if (t < 16) {
-            s_b[0][t] = br[0];
-            s_b[1][t] = br[1];
-        }
+    float w_leaf = 1.f, w_pmin = 1.f;
+    unsigned int w_rec = 1u;
+    float2 w_sib = make_float2(0.f, 0.f);
+    if (tid >= 64) {
+        conv_w_to_lds(P0, a.off, C, s_w[0], s_b[0], tid - 64, 192);
+        conv_w_to_lds(P1, a.off, C, s_w[1], s_b[1], tid - 64, 192);
     } else if (f.use_per) {
-        float2 tr[TOP_PER_LANE], qv;
-#pragma unroll
-        for (int k = 0; k < TOP_PER_LANE; ++k) {
-            const int i = tid + 64 * k;
-            tr[k] = make_float2(0.f, 0.f);
-            if (i < top) tr[k] = tree_nodes(rp)[i];
+        // wave 0, every lane with the same values: node pairs of the seven levels under the root and the query nodes in
+        // one round of loads, the Philox draw while they fly, then the whole descent out of registers (tree_descend_wave)
+        float4 top[WAVE_TOP_REGS];
+        float mass_in = 0.f;
+        uint64_t ctr = 0;
+        if (f.mass) mass_in = f.mass[b];
+        else if (f.rng) ctr = f.rng[0];               // (the draw hangs on this word: asked for first)
+        wave_top_fetch(rp, top);
+        const float2 qv = tree_query_fetch_wave(tree_nodes(rp), cap, rp.capacity, f.size);
+        double unit = 0.0;
+        if (!f.mass) {
+            uint32_t r[4];
+            Philox ph(f.seed);
+            ph(f.offset + ctr + (uint64_t)b, 0x5045524dull, r);
+            unit = u64_to_unit_double(r[0], r[1]);
         }
-        qv = tree_query_fetch(tree_nodes(rp), cap, rp.capacity, f.size);      // (levels < 32: lanes 0..63 cover every slot)
-#pragma unroll
-        for (int k = 0; k < TOP_PER_LANE; ++k) {
-            const int i = tid + 64 * k;
-            if (i < top) s_top[i] = tr[k];
-        }
-        s_scratch[tid] = qv.x;
-        s_scratch[128 + tid] = qv.y;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
         PRISM_STAMP(24);
-        if (tid == 0) {
-            const float2 pq = tree_query_fold(s_scratch, cap);
-            const float p_sum = pq.x, p_min = pq.y;
-            if (b == 0) {
-                rp.per_state[1] = p_sum;
-                rp.per_state[2] = p_min;
-                int st = 0;
-                if (!(p_sum > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PSUM;
-                if (!(p_min > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PMIN;
-                if (st) atomicOr(rp.status, st);
-            }
-            PRISM_STAMP(28);
-            float mass;
-            if (f.mass) {
-                mass = f.mass[b];
-            } else {
-                uint32_t r[4];
-                Philox ph(f.seed);
-                ph(f.offset + (f.rng ? f.rng[0] : 0ull) + (uint64_t)b, 0x5045524dull, r);
-                mass = (float)(0.0 + ((double)p_sum - 0.0) * u64_to_unit_double(r[0], r[1]));
-            }
-            // the descent reads both children of every path node; the one it does not step into is
-            // exactly what the priority writeback needs later -> record it, level-major
-            float leaf_sum = 0.f;
-            idx = tree_descend_record(rp, s_top, top, mass, s_sibrec, 1, &leaf_sum);
-            unsigned int rec = 1u;                                  // 1 = record valid, 2 = not usable
-            if (idx > f.size - 1) {
-                idx = f.size - 1;
-                leaf_sum = tree_nodes(rp)[idx | cap].x;
-                rec = 2u;
-            }
-            s_out_w = pow_neg_beta(leaf_sum / p_min, f.beta);       // stored after the n-step walk's loads
-            s_rec_state = rec;
-            s_i64[0] = idx;
+        const float2 pq = tree_query_fold_wave(qv);
+        const float p_sum = pq.x, p_min = pq.y;
+        if (b == 0 && tid == 0) {
+            rp.per_state[1] = p_sum;
+            rp.per_state[2] = p_min;
+            int st = 0;
+            if (!(p_sum > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PSUM;
+            if (!(p_min > 0.0f)) st |= PRISM_STATUS_NONPOSITIVE_PMIN;
+            if (st) atomicOr(rp.status, st);
         }
+        PRISM_STAMP(28);
+        PRISM_STAMP2(0);
+        const float mass = f.mass ? mass_in : (float)(0.0 + ((double)p_sum - 0.0) * unit);
+        // the descent reads both children of every path node; the one it does not step into is exactly what the
+        // priority writeback needs later -> recorded, level s in lane s
+        WaveDescent wd = tree_descend_wave(rp, top, mass);
+        idx = wd.idx;
+        PRISM_STAMP2(1);
+        float leaf_sum = wd.leaf_sum;
+        unsigned int rec = 1u;                                  // 1 = record valid, 2 = not usable
+        if (idx > f.size - 1) {
+            idx = f.size - 1;
+            leaf_sum = tree_nodes(rp)[idx | cap].x;
+            rec = 2u;
+        }
+        if (tid == 0) s_i64[0] = idx;
+        // (importance weight and sibling record: nobody needs them before the rows are convolved -> behind the barrier,
+        // beside the flight of the observation row)
+        w_leaf = leaf_sum;
+        w_pmin = p_min;
+        w_rec = rec;
+        w_sib = wd.sib;
     } else if (tid == 0) {
         uint32_t r[4];
         Philox ph(f.seed);
@@ -241,50 +201,141 @@ __global__ __launch_bounds__(NT) void step_front_kernel(IqnArgs a, prism_replay_
         s_i64[0] = idx;
     }
     PRISM_STAMP(29);
-    // The sampled slot is known: the first O / 4 threads request their piece of the CURRENT observation, park it in LDS and
-    // stream it to the static batch; behind the next barrier waves 4-7 convolve it while lane 0 of wave 0 walks the links.
+    // The sampled slot is known.  ONE round of loads: the first O / 4 threads their piece of the CURRENT observation, and
+    // every one of the first four waves (each for itself: no hand-off) reward / link / flags of the slot -- hop 0 of the
+    // n-step walk (timestep_buffer.py:198-238).  Interleaved environment streams link slot i to i + d with one d for the
+    // whole chain, so the link of hop 0 predicts every later hop: the SECOND round asks for reward / link / flags of the
+    // slots idx + 2d, idx + 3d, ... (hop k in lane k - 1 of wave 0) and, O / 4 threads again, for the successor
+    // observation of the slot the walk should end at.  The walk then runs out of registers and checks every link it
+    // follows against the slot that was asked for (a miss falls back to a dependent load); a walk that ends elsewhere
+    // (episode end: the successor is the observation itself; a truncation or an open chain) takes the dependent row load
+    // further down.  Two dependent round trips where the plain walk made n_step + 1; same values, same order.
     __syncthreads();
+    PRISM_STAMP2(2);
     const int O = rp.obs_elems;     // == 100 * C
-    const float *src_obs = rp.obs + s_i64[0] * O;
+    const int64_t idx0 = s_i64[0];
+    const float *src_obs = rp.obs + idx0 * O;
     float *d0 = f.obs + (int64_t)b * O, *d1 = f.next_obs + (int64_t)b * O;
-    if (tid < O / 4) {
-        const float4 xc = reinterpret_cast<const float4 *>(src_obs)[tid];
-        stream_store4(reinterpret_cast<float4 *>(d0) + tid, xc);
-        reinterpret_cast<float4 *>(s_obs[0])[tid] = xc;
+    const int n_step = rp.n_step;
+    float4 xc = make_float4(0.f, 0.f, 0.f, 0.f), xs = xc;
+    float crw = 0.f;
+    int32_t cnx = -1, act0 = 0;
+    uint32_t cfl = 0;
+    int64_t pred = -1;
+    bool pred_ok = false;
+    float rw0 = 0.f;
+    int32_t nx0 = -1;
+    uint32_t f0 = 0;
+    int64_t dlt = 0;
+    double g_lane = 0.0;
+    {
+        if (tid < O / 4) xc = reinterpret_cast<const float4 *>(src_obs)[tid];
+        {   // gamma ** lane, read from the argument segment with a per-lane index (indexing the by-value struct at run time
+            // would move it to scratch; one scalar load per hop put ~200 cycles into every step of the walk)
+            typedef const double __attribute__((address_space(4))) *cdp;
+            constexpr size_t RP_OFF = (sizeof(IqnArgs) + alignof(prism_replay_desc) - 1) / alignof(prism_replay_desc) * alignof(prism_replay_desc);
+            cdp g = (cdp)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + RP_OFF +
+                          offsetof(prism_replay_desc, gammas));
+            const int gi = (tid & 63) < n_step ? (tid & 63) : n_step;
+            g_lane = g[gi];
+        }
+        rw0 = rp.reward[idx0];
+        nx0 = rp.link[idx0];
+        f0 = rp.flags[idx0];
+        if (tid == 0) act0 = rp.action[idx0];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PRISM_STAMP2(3);
+        const bool go = (f0 & PRISM_FLAG_HAS_NEXT) && !(f0 & PRISM_FLAG_TRUNC) && n_step > 1 && nx0 >= 0;
+        dlt = (int64_t)nx0 - idx0;
+        pred = go ? idx0 + (int64_t)(n_step - 1) * dlt : idx0;
+        pred_ok = pred >= 0 && pred < rp.capacity;
+        if (tid < O / 4) {
+            obs_to_lds(s_obs[0], xc, tid, C);
+            if (pred_ok) xs = reinterpret_cast<const float4 *>(rp.succ_obs + pred * O)[tid];
+        }
+        if (go && tid < n_step - 1) {                 // (wave 0: n_step <= PRISM_MAX_NSTEP < 64)
+            const int64_t c = (int64_t)nx0 + (int64_t)tid * dlt;
+            if (c >= 0 && c < rp.capacity) {
+                crw = rp.reward[c];
+                cnx = rp.link[c];
+                cfl = rp.flags[c];
+            }
+        }
+        if (tid < O / 4) stream_store4(reinterpret_cast<float4 *>(d0) + tid, xc);
+        if (f.use_per && tid < 64) {
+            if (tid < 63 - __clzll((unsigned long long)rp.tree_capacity)) s_sibrec[tid] = w_sib;
+            if (tid == 0) {
+                s_out_w = pow_neg_beta(w_leaf / w_pmin, f.beta);
+                s_rec_state = w_rec;
+            }
+        }
     }
     lds_barrier();
-    if (NT > 256 && tid >= 256) {
-        conv_embed_rows<4>(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid - 256, 256);
-    } else if (tid == 0) {
-        const NStepResult ns = nstep_walk(rp, idx);
-        s_i64[1] = ns.last;
-        s_flags = ns.flags;
-        f.reward[b] = (float)ns.ret;
-        f.gamma[b] = (float)ns.gamma;
-        f.nonterminal[b] = (ns.flags & PRISM_FLAG_DONE) ? 0 : 1;
-        f.action[b] = (int64_t)rp.action[idx];
-        f.out_index[b] = idx;
-        if (f.use_per) {
-            f.out_weight[b] = s_out_w;
-            if (b == 0 || s_rec_state == 2u) atomicMax(a.ws.ticket + 3, s_rec_state);
+    PRISM_STAMP2(4);
+    conv_embed_rows(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid);
+    PRISM_STAMP2(5);
+    if (tid < 64) {
+        // the walk, wave-uniform (nstep_walk's arithmetic and order)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PRISM_STAMP2(6);
+        auto gam = [&](int k) {
+            const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(g_lane) & 0xffffffffll), k);
+            const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(g_lane) >> 32), k);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        };
+        int64_t cur = idx0;
+        double ret = (double)rw0 * gam(0);
+        uint32_t fl = f0;
+        int32_t nx = nx0;
+        bool go = (f0 & PRISM_FLAG_HAS_NEXT) && !(f0 & PRISM_FLAG_TRUNC) && n_step > 1 && nx0 >= 0;
+        int k = 1;
+        for (; go; ++k) {
+            cur = nx;
+            float rw;
+            if (cur == (int64_t)nx0 + (int64_t)(k - 1) * dlt) {
+                rw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(crw), k - 1));
+                nx = __builtin_amdgcn_readlane(cnx, k - 1);
+                fl = (uint32_t)__builtin_amdgcn_readlane((int)cfl, k - 1);
+            } else {
+                rw = rp.reward[cur];
+                nx = rp.link[cur];
+                fl = rp.flags[cur];
+            }
+            ret += (double)rw * gam(k);
+            go = (fl & PRISM_FLAG_HAS_NEXT) && !(fl & PRISM_FLAG_TRUNC) && k != n_step - 1 && nx >= 0;
         }
-    } else if (f.use_per && tid >= 64 && tid < 256 && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity)) {
-        // the sibling record goes out now, from lanes that have nothing in flight (level s from lane 64 + s)
+        const double gamma = gam(k);          // gamma ** (number of rewards summed)
+        if (tid == 0) {
+            s_i64[1] = cur;
+            s_flags = fl;
+            // 1 = the row that was asked for is the successor; 2 = no successor stored: the observation itself; 0 = fetch it
+            s_rec_state2 = !(fl & PRISM_FLAG_HAS_NEXT) ? 2u : (pred_ok && cur == pred) ? 1u : 0u;
+            f.reward[b] = (float)ret;
+            f.gamma[b] = (float)gamma;
+            f.nonterminal[b] = (fl & PRISM_FLAG_DONE) ? 0 : 1;
+            f.action[b] = (int64_t)act0;
+            f.out_index[b] = idx0;
+            if (f.use_per) {
+                f.out_weight[b] = s_out_w;
+                if (b == 0 || s_rec_state == 2u) atomicMax(a.ws.ticket + 3, s_rec_state);
+            }
+        }
+    } else if (f.use_per && tid - 64 < 63 - __clzll((unsigned long long)rp.tree_capacity)) {
+        // the sibling record goes out from lanes that have nothing else to do (level s from lane 64 + s)
         reinterpret_cast<float2 *>(a.ws.sib)[(int64_t)(tid - 64) * B + b] = s_sibrec[tid - 64];
     }
+    if (tid < O / 4) obs_to_lds(s_obs[1], xs, tid, C);
     PRISM_STAMP(30);
     lds_barrier();
-    const float *src_next = (s_flags & PRISM_FLAG_HAS_NEXT) ? rp.succ_obs + s_i64[1] * O : src_obs;
-    float4 xn = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < O / 4) xn = reinterpret_cast<const float4 *>(src_next)[tid];
-    if (NT == 256) conv_embed_rows<4>(s_obs[0], s_w[0], s_b[0], C, a.ws.e_cur + (int64_t)b * E_DIM, tid, 256);     // (beside the successor row's flight)
-    if (tid < O / 4) {
-        stream_store4(reinterpret_cast<float4 *>(d1) + tid, xn);
-        reinterpret_cast<float4 *>(s_obs[1])[tid] = xn;
+    const unsigned int spec = __builtin_amdgcn_readfirstlane(s_rec_state2);
+    if (spec != 1u) {
+        if (spec == 0u && tid < O / 4) xs = reinterpret_cast<const float4 *>(rp.succ_obs + s_i64[1] * O)[tid];
+        if (spec == 2u) xs = xc;
+        if (tid < O / 4) obs_to_lds(s_obs[1], xs, tid, C);
+        lds_barrier();
     }
-    lds_barrier();
-    if (NT == 256) conv_embed_rows<4>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 256);
-    else conv_embed_rows<8>(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid, 512);
+    if (tid < O / 4) stream_store4(reinterpret_cast<float4 *>(d1) + tid, xs);
+    conv_embed_rows(s_obs[1], s_w[1], s_b[1], C, a.ws.e_next + (int64_t)b * E_DIM, tid);
     PRISM_STAMP(31);
 }
 

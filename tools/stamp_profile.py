@@ -62,6 +62,19 @@ if fr[:, 0].any():
     print("front sample blocks (top+query | descent | n-step | gather+conv): med", [int(np.median(fr[:, k + 1] - fr[:, k])) for k in range(4)], "total", int(np.median(fr[:, 4] - fr[:, 0])))
 ft = s[:B, [27, 24, 28]].astype(np.float64)
 if ft[:, 1].any(): print("   top+query detail (loads + LDS staging + barrier | p_sum/p_min fold by lane 0):", [int(np.median(ft[:, k + 1] - ft[:, k])) for k in range(2)])
+rs_, re_ = s[:B, 32 + 27].astype(np.float64), s[:B, 32 + 31].astype(np.float64)
+allb = s[:, 32 + 27] != 0
+ra_, rb_ = s[allb, 32 + 27].astype(np.float64), s[allb, 32 + 31].astype(np.float64)
+if allb.any():
+    print(f"   front real time: sample blocks start spread {(rs_.max() - rs_.min()) / 100:.2f} us, first start -> last sample end {(re_.max() - rs_.min()) / 100:.2f} us; "
+          f"all {int(allb.sum())} blocks: first start -> last end {(rb_.max() - ra_.min()) / 100:.2f} us, last start at {(ra_.max() - ra_.min()) / 100:.2f} us")
+    print("   sample block real-time duration: med %.2f us p95 %.2f max %.2f" % tuple(np.percentile((re_ - rs_) / 100, [50, 95, 100])))
+f2 = s[2048:2048 + B].astype(np.float64)
+if f2[:, 0].any():
+    seq = [(s[:B, 28].astype(np.float64), "fold done"), (f2[:, 0], "mass"), (f2[:, 1], "descent"), (s[:B, 29].astype(np.float64), "weight+record"),
+           (f2[:, 2], "syncthreads"), (f2[:, 3], "trip A arrived"), (f2[:, 4], "obs in LDS + barrier"), (f2[:, 5], "conv cur"), (f2[:, 6], "trip B wait"),
+           (s[:B, 30].astype(np.float64), "walk + outputs"), (s[:B, 31].astype(np.float64), "barrier + conv next")]
+    print("   front detail:", ", ".join(f"{n} {int(np.median(y - x))}" for (x, _), (y, n) in zip(seq[:-1], seq[1:])))
 fx = s[B:B + 1024, [27, 31]].astype(np.float64)
 fx = fx[fx[:, 0] != 0]
 if len(fx): print(f"front extra blocks (u/v, weight packing): n={len(fx)} dur med {int(np.median(fx[:, 1] - fx[:, 0]))} max {int(np.max(fx[:, 1] - fx[:, 0]))}")
