@@ -40,10 +40,13 @@ static_assert(lds_layout_ok(BW3_REGIONS, BW3_LDS_BYTES), "backward (bf16): LDS i
 static_assert(BW3_PROW % 16 == 0 && BW3_CROW % 16 == 0, "16-byte aligned image rows");
 
 // conv-backward taps (IQN-only models): behind the fixed regions, per helper wave the observation rows [samples][4 rows][10][C]
-// of the chunk's samples, then the lane-group partial sums [4 waves][4 groups][TAPS + 1]
+// of the chunk's samples, then the lane-group partial sums [4 waves][4 groups][TAPS + 1], then the four helper waves'
+// finished rows [4][BWD_CONV_ROW] and their arrival count: the wave that finishes last adds the four (slice order, the
+// order the post launch used to add them in) and writes ONE row per (row chunk, channel) -- the post launch's single
+// conv workgroup then reads 16 instead of 64 partials per output
 __host__ __device__ inline int bw3_samples(int B, int T) { return (B * T / BW3_RC) / T; }
 __host__ __device__ inline int bw3_lds_bytes(int B, int T, int C, bool conv) {
-    return BW3_LDS_BYTES + (conv ? 4 * (4 * bw3_samples(B, T) * 40 * C + 4 * 4 * (BWD_CONV_TAPS + 1)) : 0);
+    return BW3_LDS_BYTES + (conv ? 4 * (4 * bw3_samples(B, T) * 40 * C + 4 * 4 * (BWD_CONV_TAPS + 1) + 4 * BWD_CONV_ROW + 4) : 0);
 }
 inline bool bw3_conv_ok(int use_iqn, int n_heads, int propagate_grad, int T, int C, int B) {
     const int share = bwd_conv_share(T);
@@ -89,6 +92,9 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
         const int ws_lo = row0 / T, ws_n = n_mine ? rpc / T : 0;
         float *s_obs = reinterpret_cast<float *>(smem + BW3_LDS_BYTES) + wq * (ws_n * 40 * C);
         float *s_tap = reinterpret_cast<float *>(smem + BW3_LDS_BYTES) + 4 * (ws_n * 40 * C);
+        float *s_row = s_tap + 4 * 4 * (BWD_CONV_TAPS + 1);
+        unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_row + 4 * BWD_CONV_ROW);
+        if (n_mine && ht_tid == 0) *s_cnt = 0u;          // (the block loop's barriers lie between this and the first arrival)
         float4 pd[4], pc[2];
         auto request = [&](int blk) __attribute__((always_inline)) {
             const int r0 = row0 + blk * BW3_RB;
@@ -187,7 +193,18 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
                 const int so = lane < 9 * C ? lane / n_mine : 0, i = lane < 9 * C ? lane - so * n_mine : BWD_CONV_TAPS;
                 float tsum = s_tap[(wq * 4 + so) * TS + i];
                 if (T == 8) tsum += s_tap[(wq * 4 + so + 2) * TS + i];
-                a.ws.convpart[(int64_t)(rc * (E_DIM / 16) + cs) * BWD_CONV_ROW + lane] = tsum;
+                s_row[wq * BWD_CONV_ROW + lane] = tsum;
+            }
+            // last of the four helper waves to get here folds (LDS operations of a wave retire in order: a wave's row is
+            // in place before its count is)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int arrived = 0;
+            if (lane == 0) arrived = (int)__hip_atomic_fetch_add(s_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == 3 && lane <= 9 * C) {
+                const float *r = s_row + lane;
+                a.ws.convpart[(int64_t)(rc * (E_DIM / 16) + (cs & ~3)) * BWD_CONV_ROW + lane] =
+                    ((r[0] + r[BWD_CONV_ROW]) + r[2 * BWD_CONV_ROW]) + r[3 * BWD_CONV_ROW];
             }
         }
         PRISM_STAMP(26);

@@ -105,6 +105,7 @@ struct IqnArgs {
     int has_target, double_q, propagate_grad;
     int use_iqn, n_heads;  // Q ensemble: 0 = none
     int conv_in_bwd;       // conv-backward partials are produced by the tail of iqn_bwd_kernel (bwd_conv_ok)
+    int conv_rows;         // ... as this many partial rows per (row chunk, channel): 4 column slices, or 1 (already added)
     BwdGeom bg;
     int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
     int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
@@ -1164,6 +1165,11 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
     }
 }
 
+// A gradient element another workgroup of the SAME launch reads behind the fused tail's grid barrier: stored at agent
+// scope (written through, past this XCD's L2), so that the producer's barrier arrival needs no L2 write-back -- it only
+// waits for these stores.  The reader uses agent-scope loads (tail_clip_adam).
+__device__ __forceinline__ void far_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // b1, LN2 affine, W2, b2 gradients of one [LN -> Linear(H -> A)] head for the 16 hidden units
 // [slice*16, slice*16+16), shared by the IQN head and the Q-ensemble heads:
 //   S[a][h] = sum_{b: act=a} v(b,h);  D[a] = sum_{b: act=a} d(b);  db1[h] = sum_b p(b,h)
@@ -1212,7 +1218,9 @@ __device__ __forceinline__ void small_fold_core(const IqnArgs &a, int slice, flo
     for (int aa = 0; aa < AMAX; ++aa) sA[aa] = dA[aa] = 0.f;
     float pb = 0.f;
     float lw = (io.extra && slice == 0 && tid < B) ? io.extra[tid] : 0.f;
-#pragma unroll 8
+    // (four trips at batch 256: unrolled by exactly that -- under "unroll 8" those four ran in the ROLLED remainder loop,
+    // one memory round trip each, and this role reached the fused tail's grid barrier last)
+#pragma unroll 4
     for (int b = part; b < B; b += 64) {
         const float3 x = load(b, h, hl == 0);                   // d rides in column 16 of the fold
         pb += x.y;
@@ -1269,7 +1277,7 @@ __device__ __forceinline__ void small_fold_core(const IqnArgs &a, int slice, flo
         const float S = s_S[ta][hl], D = s_D[ta];
         float dw = g2 * S + be2 * D;
         if (io.use_kappa) dw += k * w2;
-        io.gw2[(int64_t)ta * io.w_stride + h] = dw;
+        far_store(&io.gw2[(int64_t)ta * io.w_stride + h], dw);
         sq += dw * dw;
         dg = w2 * S;
         db = w2 * D;
@@ -1285,20 +1293,20 @@ __device__ __forceinline__ void small_fold_core(const IqnArgs &a, int slice, flo
             float t = 0.f;
             for (int aa = 0; aa < A; ++aa) t += s_dgb[which][aa][hl];
             if (io.use_kappa) t += k * (which ? io.be2[h] : io.g2[h]);
-            (which ? io.gbe2 : io.gg2)[h] = t;
+            far_store(&(which ? io.gbe2 : io.gg2)[h], t);
             sq += t * t;
         }
     } else if (tid < 3 * SMALL_W && io.gb1) {
         float t = s_S[A][hl];
         if (io.use_kappa) t += k * b1v;
-        io.gb1[h] = t;
+        far_store(&io.gb1[h], t);
         sq += t * t;
     }
     PRISM_STAMP(19);
     if (slice == 0 && tid < A) {
         float D = s_D[tid];
         if (io.use_kappa) D += k * b2v;
-        io.gb2[tid] = D;
+        far_store(&io.gb2[tid], D);
         sq += D * D;
     }
     if (io.extra && slice == 0 && tid == 0) {

@@ -324,6 +324,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.q_de_slots = d.n_heads;
     if (a.split && qb2_ok(a.Hq, B, d.n_heads, d.head_layers)) a.q_de_slots = 2;
     a.conv_in_bwd = conv_in_bwd(ld);
+    a.conv_rows = use_bw3(ld) ? 1 : 4;
     a.bg = bwd_geometry(a.Hi, a.B, a.C, a.T, a.n_chunks, a.conv_in_bwd != 0);
     a.huber_k = d.huber_k;
     a.dist_w = d.dist_loss_weight;

@@ -365,9 +365,9 @@ __host__ __device__ inline int post_blocks_dqn1(int C) { return dqn1_conv_blocks
 __device__ __forceinline__ float block_sum_1024(float v, float *s_red) {
     const int tid = threadIdx.x;
     v = wave_sum(v);
-    __syncthreads();
+    lds_barrier();              // (LDS only: a __syncthreads() here also waits for every store the caller has in flight)
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     float t = 0.f;
     if (tid < 16) t = s_red[tid];
     if (tid < 64) {
@@ -501,13 +501,26 @@ constexpr unsigned int GRID_STATUS_TIMEOUT = 1u;
 __device__ __forceinline__ unsigned long long grid_barrier_weight(unsigned int n) {
     return blockIdx.x == 0 ? GRID_EPOCH - (unsigned long long)(n - 1) : 1ull;
 }
-__device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long long *bar, unsigned int n) {
+// `how` = 2, light: the workgroup hands NOTHING to the others through ordinary stores (its only cross-workgroup word was
+// written at agent scope by thread 0, which waits for that one store): no drain of the other waves, no L2 write-back.
+// `how` = 1: everything the others read was stored at agent scope (far_store): every wave waits for its own stores, the
+// workgroup meets, no L2 write-back.  `how` = 0: the full release.
+__device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long long *bar, unsigned int n, int how = 0) {
+    unsigned long long old = 0;
+    if (how == 2) {
+        if (threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            old = atomicAdd(bar, grid_barrier_weight(n));
+        }
+        return old;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned long long old = 0;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (how == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         old = atomicAdd(bar, grid_barrier_weight(n));
     }
     return old;
@@ -561,6 +574,8 @@ struct TailShare {
     float4 g;         // the owned gradient
     int64_t k, kstride, nleft, s0, cnt;     // leftover walk (kstride 0: none)
     bool scalar_tail; // this block also updates the n & 3 trailing elements
+    float *gout;      // slab blocks: the flat gradient, to which the owned sums are written behind the arrival; else NULL
+    int arrive;       // 0 full release, 1 drain only (every cross-read store was written through), 2 light (see grid_barrier_arrive)
 };
 
 // Clip + Adam behind the grid barrier (1024 threads).  Everything that does not depend on the other workgroups is
@@ -583,7 +598,8 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long 
     // (the step count was requested at kernel entry; it has to have ARRIVED before this workgroup is counted in --
     // workgroup 0 overwrites it behind the barrier)
     asm volatile("" ::"s"((int)step_now), "s"((int)(step_now >> 32)));
-    const unsigned long long ticket = grid_barrier_arrive(barrier, (unsigned)n_role);
+    const unsigned long long ticket = grid_barrier_arrive(barrier, (unsigned)n_role, sh.arrive);
+    if (sh.gout && sh.own) stream_store4(reinterpret_cast<float4 *>(sh.gout) + sh.j, sh.g);
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), m0 = p0, v0 = p0;
     if (sh.have) {
         p0 = reinterpret_cast<const float4 *>(a.p)[sh.j];
@@ -726,6 +742,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     int blk = blockIdx.x;
     float sq = 0.f;
     float4 g_own = make_float4(0.f, 0.f, 0.f, 0.f);     // (fused tail) the slab sum of this thread, kept for its Adam update
+    bool far_all = false;       // every store of this role that another workgroup reads behind the barrier was a far_store
     if (dqn1 && blk < n_conv) {
         // fold the per-sample rows of the loss kernel: 64 outputs x 16 batch parts per workgroup
         float *s_part = reinterpret_cast<float *>(s_pool);           // [16][CONV_FOLD_W]
@@ -749,17 +766,39 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         // the backward kernel left one partial row per (row chunk rc, column slice cs): channel c owns
         // slices 4c..4c+3.  Fold them in fixed order (rc outer, slice inner).
         const int nk = 9 * C, n_out = 16 * nk + 16, n_cs = E_DIM / 16;
+        PRISM_STAMP(20);
+        // every partial requested before the first add (one row chunk per trip of a rolled loop was sixteen dependent
+        // round trips).  a.conv_rows: partial rows per (row chunk, channel) -- the 64-column backward adds its four column
+        // slices itself (1), the 16-column one leaves them to this fold (4): 64 scalar loads in each of ten waves were
+        // 10 k cycles of this one CU's address unit, and the whole grid waits for this workgroup
         for (int o = tid; o < n_out; o += 1024) {
             const int c = o < 16 * nk ? o / nk : o - 16 * nk, k = o < 16 * nk ? o - c * nk : nk;
             const float *src = a.ws.convpart + (int64_t)(4 * c) * BWD_CONV_ROW + k;
             float t = 0.f;
-            for (int rc = 0; rc < a.n_chunks; ++rc) {
-                const float *r = src + (int64_t)rc * n_cs * BWD_CONV_ROW;
-                t += ((r[0] + r[BWD_CONV_ROW]) + r[2 * BWD_CONV_ROW]) + r[3 * BWD_CONV_ROW];
+            if (a.conv_rows == 1) {
+                float v[16];
+#pragma unroll
+                for (int rc = 0; rc < 16; ++rc) v[rc] = src[(int64_t)(rc < a.n_chunks ? rc : 0) * n_cs * BWD_CONV_ROW];
+#pragma unroll
+                for (int rc = 0; rc < 16; ++rc)
+                    if (rc < a.n_chunks) t += v[rc];
+            } else {
+                float v[16][4];
+#pragma unroll
+                for (int rc = 0; rc < 16; ++rc) {
+                    const float *r = src + (int64_t)(rc < a.n_chunks ? rc : 0) * n_cs * BWD_CONV_ROW;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[rc][q] = r[q * BWD_CONV_ROW];
+                }
+#pragma unroll
+                for (int rc = 0; rc < 16; ++rc)
+                    if (rc < a.n_chunks) t += ((v[rc][0] + v[rc][1]) + v[rc][2]) + v[rc][3];
             }
-            a.grads[(o < 16 * nk ? a.off.conv_w : a.off.conv_b - 16 * nk) + o] = t;
+            far_store(&a.grads[(o < 16 * nk ? a.off.conv_w : a.off.conv_b - 16 * nk) + o], t);
             sq += t * t;
         }
+        far_all = true;
+        PRISM_STAMP(21);
     } else if (blk < n_conv) {
         __shared__ int s_last;
         conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
@@ -842,13 +881,16 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 if (in && half == 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     PRISM_STAMP(7);
-                    stream_store4(reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i), s);
+                    // (fused tail: the owner keeps the sum in registers for its Adam update and writes the gradient out
+                    // BEHIND its barrier arrival -- nobody else reads it, and a store in flight is a store to drain)
+                    if constexpr (!TAIL) stream_store4(reinterpret_cast<float4 *>(a.grads + a.off.phi_w + 4 * (int64_t)i), s);
                     sq = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
                     g_own = s;
                 }
                 done = true;
             } else if (blk < n_slab + n_small) {
                 small_tensor_block(a, blk - n_slab, sq, reinterpret_cast<float *>(s_pool));
+                far_all = true;
                 done = true;
             } else {
                 blk -= n_slab + n_small;
@@ -911,7 +953,8 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         }
     }
     const float t = block_sum_1024(sq, s_red);
-    if (tid == 0) a.ws.normpart[blockIdx.x] = t;
+    // (agent scope: written through to where the other XCDs' agent-scope loads look for it, whatever release follows)
+    if (tid == 0) __hip_atomic_store(a.ws.normpart + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0 && tid == 0 && a.has_target) a.ws.ticket[2] = 1u;      // the front / embed launch of this update packed the target set
     PRISM_STAMP(14);
     if constexpr (TAIL) {
@@ -930,9 +973,13 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             sh.j = sh.s0 + i;
             sh.k = sh.kstride = 0;
             sh.scalar_tail = false;
+            sh.gout = a.grads;
+            sh.arrive = 2;
         } else {
             const int rank = (int)blockIdx.x < n_conv ? (int)blockIdx.x : (int)blockIdx.x - n_slab;
             sh.own = false;
+            sh.gout = nullptr;
+            sh.arrive = far_all ? 1 : 0;
             sh.k = (int64_t)rank * 1024 + tid;
             sh.kstride = (int64_t)(n_role - n_slab) * 1024;
             sh.have = sh.k < sh.nleft;

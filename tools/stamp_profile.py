@@ -88,12 +88,15 @@ print(f"post ({pb.sum()} blocks): span {pe_.max() - t0:9.0f} ticks")
 def rep(name, m):
     if m.any():
         print(f"   {name:12s} n={m.sum():4d} start {np.median(ps_[m]-t0):8.0f}  dur med {np.median(pe_[m]-ps_[m]):8.0f} max {np.max(pe_[m]-ps_[m]):8.0f}  end max {np.max(pe_[m])-t0:8.0f}")
+# IQN-only layout: conv | slab sums | 8 small-tensor blocks (16 hidden units each) | writeback
+n_small = cfg.iqn_hidden_layer_width // 16 if hasattr(cfg, "iqn_hidden_layer_width") else 8
+n_slab = int(idx.max()) - n_conv - n_small
 rep("conv", idx < n_conv)
-rep("slab", (idx >= n_conv) & (idx < n_conv + 49))
-rep("small", (idx >= n_conv + 49) & (idx < n_conv + 57))
-rep("rest", (idx >= n_conv + 57) & (idx < idx.max()))
-sm = s[n_conv + 49:n_conv + 57].astype(np.float64)
+rep("slab", (idx >= n_conv) & (idx < n_conv + n_slab))
+rep("small", (idx >= n_conv + n_slab) & (idx < n_conv + n_slab + n_small))
+sm = s[n_conv + n_slab:n_conv + n_slab + n_small].astype(np.float64)
 cv = s[:n_conv].astype(np.float64)
+if n_conv == 1 and cv[0, 20]: print("   conv fold block (entry -> role | fold loads + sums | norm partial + arrival):", [int(x) for x in (cv[0, 20] - cv[0, 13], cv[0, 21] - cv[0, 20], cv[0, 14] - cv[0, 21])])
 if n_conv > 1: print("   conv phases (partials | publish+ticket | rest): med", [int(np.median(x)) for x in (cv[:, 20] - cv[:, 13], cv[:, 21] - cv[:, 20], cv[:, 14] - cv[:, 21])], "max", [int(np.max(x)) for x in (cv[:, 20] - cv[:, 13], cv[:, 21] - cv[:, 20], cv[:, 14] - cv[:, 21])])
 if n_conv > 1: print("   conv partials (stage | mac | reduce): med", [int(np.median(x)) for x in (cv[:, 22] - cv[:, 13], cv[:, 23] - cv[:, 22], cv[:, 20] - cv[:, 23])])
 print("   small phases (load | D | action rounds | b1+W2 tail | end):", [int(np.median(sm[:, 16 + k] - (sm[:, 13] if k == 0 else sm[:, 15 + k]))) for k in range(4)], int(np.median(sm[:, 14] - sm[:, 19])))
@@ -104,7 +107,7 @@ order = np.argsort(-d_)[:10]
 print("   longest post blocks (index: ticks):", ", ".join(f"{int(idx[i])}: {int(d_[i])}" for i in order))
 print("   post block duration by index decile:", [int(np.median(d_[(idx >= lo_) & (idx < hi_)])) if ((idx >= lo_) & (idx < hi_)).any() else 0
       for lo_, hi_ in zip(np.linspace(0, idx.max() + 1, 11)[:-1], np.linspace(0, idx.max() + 1, 11)[1:])])
-sl = s[n_conv:n_conv + 49].astype(np.float64)
+sl = s[n_conv:n_conv + n_slab].astype(np.float64)
 if sl[:, 7].any():
     print("   slab phases (kernel entry -> role code reached | 8 chunk loads arrived | store + norm partial written):",
           [int(np.median(x)) for x in (sl[:, 8] - sl[:, 13], sl[:, 7] - sl[:, 8], sl[:, 14] - sl[:, 7])])

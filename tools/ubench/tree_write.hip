@@ -29,14 +29,14 @@ int main() {
     hipMemcpy(idx, hidx.data(), B * 8, hipMemcpyHostToDevice); hipMemcpy(pr, hp.data(), B * 4, hipMemcpyHostToDevice);
     set_stamp<<<1, 1>>>(st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int threads : {256, 512, 1024}) {
-        for (int it = 0; it < 5; ++it) per_update_kernel<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
+    for (int threads : {256, 1024}) for (int dense = 0; dense < 2; ++dense) {
+        for (int it = 0; it < 5; ++it) (dense ? per_update_kernel<true> : per_update_kernel<false>)<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
         hipEventRecord(e0);
-        for (int it = 0; it < 100; ++it) per_update_kernel<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
+        for (int it = 0; it < 100; ++it) (dense ? per_update_kernel<true> : per_update_kernel<false>)<<<1, threads>>>(rp, idx, pr, B, 0.5f, 1e-8f, 1);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long h[64]; hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost);
-        printf("threads %4d: %.2f us/launch; stamps:", threads, ms * 10.f);
+        printf("threads %4d dense %d: %.2f us/launch; stamps:", threads, dense, ms * 10.f);
         for (int k = 1; k < 40; ++k) if (h[k]) printf(" %d:%llu", k, h[k] - h[0]);
         printf("\n");
     }
