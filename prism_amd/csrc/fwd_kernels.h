@@ -148,9 +148,22 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
 
     int hd = 0, b0 = 0;
     if (kind == 1) {
+        // Workgroups go to the eight XCDs round-robin by workgroup index, and an XCD's 4 MB L2 holds the streamed weights of
+        // five heads at most (786 KB each as bf16 pieces): in head-major tile order every XCD streams EVERY head and, with
+        // ten of them, keeps missing (188 MB of HBM-side traffic per launch for c4).  So the tiles of this pass are dealt
+        // XCD-major: the workgroups of XCD x take a contiguous run of the head-major order -- one or two heads an XCD.
+        const int n = pp->n_tiles, base = (int)blockIdx.x - tile;
+        const int x = (int)blockIdx.x & 7, first = (x - base) & 7;            // first pass tile of this XCD
+        int before = 0;                                                       // pass tiles of the XCDs below x
+#pragma unroll
+        for (int y = 0; y < 7; ++y) {
+            const int fy = (y - base) & 7;
+            before += (y < x && fy < n) ? (n - fy + 7) >> 3 : 0;
+        }
+        const int v = before + ((tile - first) >> 3);
         const int tiles_per_head = B / 16;
-        hd = tile / tiles_per_head;
-        b0 = (tile - hd * tiles_per_head) * 16;
+        hd = v / tiles_per_head;
+        b0 = (v - hd * tiles_per_head) * 16;
     }
     auto row_of = [&](int m) __attribute__((always_inline)) {
         FwRow r;
