@@ -27,6 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0             # HBM3E spec
 
 
@@ -240,6 +241,12 @@ def main():
         learner.configure(cfg, obs_shape=(10, 10, 4), n_actions=6, process_group=pg)
     learner.time_phases = False
     buf, agent = learner.experience_buffer, learner.agent
+    # which matrix pipe the GEMMs run on: the config knob, else PRISM_GEMM, else the library default
+    gemm_mode = str(getattr(cfg, "gemm_mode", "auto"))
+    if gemm_mode not in ("fp32", "bf16x3"):
+        gemm_mode = os.environ.get("PRISM_GEMM", "")
+    if gemm_mode not in ("fp32", "bf16x3"):
+        gemm_mode = "bf16x3"          # PRISM_GEMM_DEFAULT (include/prism_hip.h)
     from prism_amd.dist import rank_seeds
     _, buf.seed, agent.seed = rank_seeds(cfg.seed, rank)
     fill_replay(buf, buf.capacity, seed=rank)
@@ -342,6 +349,13 @@ def main():
                 roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": traffic_all.get(dom), "flops_per_launch": fl[dom]}
+                if gemm_mode == "bf16x3":
+                    # the same fp32-accurate products, executed as six bf16 piece products each on the bf16 pipe
+                    roof["pipe"] = {"gemm_mode": "bf16x3", "executed_TFLOPs": round(6 * ach, 1), "bf16_dense_peak": BF16_MFMA_PEAK_TFLOPS,
+                                    "executed_frac_of_bf16_peak": round(6 * ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                                    "note": "achieved / peak / frac above count ALGORITHMIC fp32 flops against the fp32-MFMA peak "
+                                            "(the rate an exact-fp32 path is priced at); every fp32 operand is three bf16 pieces, six "
+                                            "piece products per product, fp32 accumulate (DESIGN.md 4.1)"}
             else:       # DQN configurations: no GEMM; the longest kernel is a latency-bound byte mover
                 dom = max((k for k in kern if k in kbytes), key=lambda k: kern[k])
                 ach = kbytes[dom] / (kern[dom] * 1e-6) / 1e9
@@ -380,6 +394,8 @@ def main():
                "repeats": repeats, "timing": "median of `repeats` blocks of `steps` steps; min/max block ms_per_step: "
                f"{min(blocks) / args.steps * 1e3:.5f}/{max(blocks) / args.steps * 1e3:.5f}",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "dtype_note": f"fp32 operands, fp32 accumulation, fp32-accurate results (gemm_mode {gemm_mode}: "
+                             + ("each product as six bf16 piece products on the bf16 matrix pipe" if gemm_mode == "bf16x3" else "fp32 MFMA") + ")",
                "data": "synthetic",
                "config": {"workload": f"configs[{args.config}]: " + ["DQN + uniform replay, batch=32",
                                                                      "DQN + PER, batch=256",

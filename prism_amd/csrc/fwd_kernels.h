@@ -197,6 +197,11 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     const gcf tau_src = (kind == 2 && trow.nx) ? ps_tau_in2 : ps_tau_in;
     const int tau_sid = (kind == 2 && trow.nx) ? 1 : ps_stream_id;
 
+    // the tau counter of the device RNG: a cold word the quantile draw hangs on -- requested before everything else (asked
+    // for where it is used, inside the prologue's tid < 16 branch, its round trip sat in front of the Philox rounds, the
+    // cosines and two barriers)
+    unsigned long long rng_tau = 0ull;
+    if (kind != 1 && a.rng) rng_tau = ((const unsigned long long __attribute__((address_space(1))) *)a.rng)[1];
     // head Linear weight [A][H] and bias: the oldest requests of the kernel, so that waiting for them later
     // waits for nothing else (clamped indices: unconditional loads)
     float w2r[H / 32], b2r;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                 } else {
                     uint32_t rr[4];
                     Philox ph(a.seed);
-                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
+                    ph(a.offset + rng_tau + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
                     tau = u32_to_unit_float(rr[0]);
                 }
                 if (a.tau_out && r.t < T) a.tau_out[(int64_t)sid * a.maxT * a.Bt + (int64_t)r.t * a.Bt + r.b] = tau;
@@ -408,6 +413,17 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         auto slot = [&](int ds, int group, int plane) __attribute__((always_inline)) { return wp[((ds * G + group) * 3 + plane) * 64]; };
         const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
         const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
+        // prepared quantile samples + basis pieces of this tile (cos_basis_block): the first requests of the stream
+        const unsigned int __attribute__((address_space(1))) *cpk =
+            PHI ? (const unsigned int __attribute__((address_space(1))) *)pp->cospk : nullptr;
+        unsigned int c_h = 0, c_m = 0, c_l = 0, tbits = 0;
+        if (PHI && cpk) {
+            const unsigned int __attribute__((address_space(1))) *blk = cpk + (size_t)tile * CP_TILE + (tid >> 5) * 32 + (tid & 31);
+            c_h = blk[0];
+            c_m = blk[16 * 32];
+            c_l = blk[2 * 16 * 32];
+            if (tid < 16) tbits = cpk[(size_t)tile * CP_TILE + 3 * 16 * 32 + tid];
+        }
         u32x4 wph[2][3], w1r[RW][3];
         f32x4 e4[2], b4[2];                    // [n-tile] of the double step whose epilogue comes next (refilled by it: one
                                                // double step, 2 k cycles, ahead of their use)
@@ -432,7 +448,17 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         if (tid < A) rowf[96 + tid] = b2r;
 
         unsigned int *cosp = reinterpret_cast<unsigned int *>(cost);       // [3][16][FW_CBS] dwords of bf16 pairs
-        if (PHI) {
+        if (PHI && cpk) {
+            // quantile samples and basis pieces prepared by the embed / front launch (cos_basis_block): one round of loads
+            // and one barrier where the tile's own draw + cosines + split were 7 k cycles in front of its first MFMA
+            static_assert(NTHREADS == 512, "one basis pair per thread");
+            const int m = tid >> 5, kp = tid & 31;
+            cosp[(0 * 16 + m) * FW_CBS + kp] = c_h;
+            cosp[(1 * 16 + m) * FW_CBS + kp] = c_m;
+            cosp[(2 * 16 + m) * FW_CBS + kp] = c_l;
+            if (tid < 16) rowf[tid] = __uint_as_float(tbits);
+            lds_barrier();
+        } else if (PHI) {
             if (tid < 16) {
                 const FwRow r = trow;
                 const int sid = tau_sid;
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                 } else {
                     uint32_t rr[4];
                     Philox ph(a.seed);
-                    ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
+                    ph(a.offset + rng_tau + (uint64_t)((int64_t)r.t * a.Bt + r.b), 0x54415530ull + (uint64_t)sid, rr);
                     tau = u32_to_unit_float(rr[0]);
                 }
                 if (a.tau_out && r.t < T) a.tau_out[(int64_t)sid * a.maxT * a.Bt + (int64_t)r.t * a.Bt + r.b] = tau;
@@ -765,14 +791,21 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             vbv[4 * k + c] = vb4[k][c];
         }
     }
+    // (the sample's scalars too: behind the barrier their round trip -- cold words the front launch streamed out -- was
+    // half of the loss phase)
+    const int b_l = tile * ns + (w < ns ? w : 0);
+    const int act_l = (int)a.action[b_l];
+    const float R_l = a.reward[b_l], gam_l = a.gamma[b_l];
+    const bool nt_l = a.nonterminal[b_l] != 0;
+    const float wb_l = a.per_weights ? a.per_weights[b_l] : 1.0f;
     lds_barrier();
     if (w < ns) {
         // one wave per sample: a* = argmax_a mean_j Zon[j][a] (first maximum wins, iqn_model.py:129-133)
-        const int smp = w, rb = smp * 2 * T, b = tile * ns + smp;
-        const int act = (int)a.action[b];
-        const float R = a.reward[b];
-        const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
+        const int smp = w, rb = smp * 2 * T, b = b_l;
+        const int act = act_l;
+        const float R = R_l;
+        const float dg = gam_l * (nt_l ? 1.0f : 0.0f);
+        const float wb = wb_l;
         const float kap = a.huber_k;
         float mean = 0.f;
         {

@@ -32,6 +32,8 @@ constexpr int K_BASIS = 64;   // iqn_n_basis_elements
 constexpr int MAX_H = 256;    // hidden widths covered: 128 (MINATAR_CONFIG) and 256 (ablation presets)
 constexpr int CS = K_BASIS + 4;   // LDS row stride (floats) of a cos tile, +4 breaks the 16-row bank alias
 constexpr float LN_EPS = 1e-5f;
+// one forward tile's prepared basis: [3 planes hi | mid | lo][16 rows][32 bf16 pairs] + [16] tau (float bits)
+constexpr int CP_TILE = 3 * 16 * 32 + 16;
 constexpr float PI_F = 3.14159274101257324f;  // fp32(np.pi), the scalar torch multiplies by
 
 struct IqnPass {
@@ -42,6 +44,8 @@ struct IqnPass {
     const float *e2;      // kind 2: embedded NEXT observations (the tile's next-state rows)
     const float *tau_in;  // [T*B] tau-major, or NULL -> Philox
     const float *tau_in2; // kind 2: next-state quantile samples
+    const unsigned int *cospk; // tiles of this pass prepared by cos_basis_block (CP_TILE dwords each), or NULL: the tile draws tau
+                               // and evaluates the basis itself
     float *z_out;         // [B*T][A] sample-major
     float *z_out2;        // kind 2: next-state estimates
     int T;
@@ -56,6 +60,7 @@ struct IqnWs {           // workspace pointers (device)
     float *uv;           // [2 sets][UV_ROWS][Hi]: u = W1 g1 | v = W1 beta1 | u of each 128-column K slice, online / target IQN trunk
     float *wpk[2];       // [online, target] stream-packed {phi_w, w1 * ln1_g}
     float *cosb, *mu1, *rstd1, *pre1, *xhat2, *rstd2;
+    unsigned int *cospk; // [IQN tiles of the learner's passes][CP_TILE]: quantile samples + cos basis as bf16 pieces (cos_basis_block)
     float *phis;         // ReLU(phi) of the current-state rows for the backward: [row / 16][column / 16][16 rows][16 columns]
     float *zcur, *zon, *ztg;
     float *dq, *c1, *c2, *dpre1, *Sb, *Pb, *Db, *lossw;
@@ -108,6 +113,7 @@ struct IqnArgs {
     int conv_rows;         // ... as this many partial rows per (row chunk, channel): 4 column slices, or 1 (already added)
     BwdGeom bg;
     int local_loss;        // the IQN loss ran inside the forward tiles (kind 2): no iqn_loss_kernel launch
+    int cos_tiles;         // IQN forward tiles whose quantile samples + cos basis the embed / front launch prepares (cos_basis_block)
     int head_layers;       // 2: [LN]-Linear-ReLU-[LN]-Linear heads (MFMA path); 1: single Linear DQN head
     float q_w, theil_coef;
     int q_de_slots;        // slots of ws.de_q that hold a share of the Q heads' embedding gradient (one per head, or the

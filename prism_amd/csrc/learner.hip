@@ -169,6 +169,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.wpk[0] = c.f(iqn_pack_split_floats((int)Hi));      // (the larger of the two layouts: fp32 stream order / bf16 pieces)
     w.wpk[1] = c.f(iqn_pack_split_floats((int)Hi));
     w.cosb = c.f(R * K_BASIS);
+    w.cospk = (unsigned int *)c.f((size_t)((R + 2 * Rn + 15) / 16 + 3) * CP_TILE);
     w.phis = c.f(((R + 15) / 16) * 16 * (size_t)E_DIM);
     w.mu1 = c.f(R);
     w.rstd1 = c.f(R);
@@ -335,7 +336,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.theil_coef = d.n_heads > 1 ? d.theil_coef : 0.f;
     { const char *e = getenv("PRISM_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.stamps = (unsigned long long *)ld->dbg_stamps;
-    if (!a.stamps) a.dbg &= ~24;
+    if (!a.stamps) a.dbg &= ~(8 | 16 | 32);
     a.off = ld->off;
     a.params = ld->params;
     a.target_params = ld->target_params;
@@ -434,6 +435,15 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
         else if (!d.double_q) a.ws.zq_on = a.ws.zq_tg;
     }
     a.n_pass = np;
+    // the IQN tiles' quantile samples + cos basis come prepared from the embed / front launch (bf16 mode: the prologue they
+    // replace is the split forward's)
+    a.cos_tiles = 0;
+    if (a.split)
+        for (int i = 0; i < np; ++i)
+            if (a.pass[i].kind != 1) {
+                a.pass[i].cospk = a.ws.cospk + (size_t)a.cos_tiles * CP_TILE;
+                a.cos_tiles += a.pass[i].n_tiles;
+            }
 }
 
 static void fill_adam_args(const prism_learner_desc *ld, const IqnWs &ws, AdamArgs &a) {
@@ -751,6 +761,7 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
     fill_iqn_args(ld, a);
     hipError_t herr = hipSuccess;
     // embed (+ the parameter-only roles): the n observations stand in for both batch halves
+    a.cos_tiles = 0;          // (acting tiles draw and evaluate their basis themselves: no learner passes here)
     a.B = n;
     a.obs = a.next_obs = obs;
     hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * n + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a);

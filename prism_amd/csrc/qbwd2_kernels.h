@@ -26,6 +26,15 @@
 #include "qhead_kernels.h"
 
 namespace prism {
+// (own debug bit: this kernel's stamps share slots 0..6 with the forward tiles')
+#define QB2_STAMP(k)                                                                       \
+    do {                                                                                   \
+        if ((a.dbg & 32) && threadIdx.x == 0) {                                            \
+            a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();        \
+            a.stamps[(size_t)blockIdx.x * 64 + 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                  \
+    } while (0)
+
 
 constexpr int QB2_H = 128;
 constexpr int QB2_KS = 32;                        // K per step = K of one bf16 MFMA
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, xh = xcd >> 2, xq = xcd & 3;
     const int g_slots = qb2_g_slots(Hd);
     typedef const float4 *cf4;
-    PRISM_STAMP(0);
+    QB2_STAMP(0);
     if (slot < g_slots) {
         // =========================== G role: G_h = dpre1_h^T . xhat for 64 columns ===========================
         const int hd = xh * ((Hd + 1) / 2) + (slot >> 2), n0 = 64 * (4 * xq + (slot & 3));
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
         request(0);
         stage(smem);
         __syncthreads();
-        PRISM_STAMP(1);
+        QB2_STAMP(1);
         const int nk = B / QB2_KS;
         for (int ks = 0; ks < nk; ++ks) {
             char *cur = smem + (ks & 1) * QB2_G_BUF, *nxt = smem + ((ks + 1) & 1) * QB2_G_BUF;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
             if (ks + 1 < nk) stage(nxt);
             __syncthreads();
         }
-        PRISM_STAMP(2);
+        QB2_STAMP(2);
         // ---- epilogue.  cs: fold the 8 row groups of the staging threads (tid >> 5) in fixed order through LDS
         float *s_cs = reinterpret_cast<float *>(smem);          // [8][128]
         float *s_red = s_cs + 8 * 128;                          // [2 quantities][2 (wm)][64 n]
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
                 slab[which * E_DIM + n0 + n] = s_red[(which * 2 + 0) * 64 + n] + s_red[(which * 2 + 1) * 64 + n];
             }
         }
-        PRISM_STAMP(3);
+        QB2_STAMP(3);
         return;
     }
     // =========================== S role: S = P . Wg over half of the heads, 64 rows x 64 columns ===========================
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
         request(0);
         stage(smem);
         __syncthreads();
-        PRISM_STAMP(1);
+        QB2_STAMP(1);
         for (int ks = 0; ks < nk; ++ks) {
             char *cur = smem + (ks & 1) * QB2_S_BUF, *nxt = smem + ((ks + 1) & 1) * QB2_S_BUF;
             if (ks + 1 < nk) request(ks + 1);
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
             if (ks + 1 < nk) stage(nxt);
             __syncthreads();
         }
-        PRISM_STAMP(2);
+        QB2_STAMP(2);
         // ---- epilogue: this K half's share of the embedding gradient (the LayerNorm terms ride with half 0).  The row
         // scalars -- rstd, and for half 0 mean and the sums over the heads of c1 / c2 (heads in order) -- are gathered once
         // per workgroup: thread = (row, head) requests, then one thread per row folds
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void qh_bwd2_kernel(IqnArgs a) {
                     de[(size_t)b * E_DIM + n] = v;
                 }
             }
-        PRISM_STAMP(3);
+        QB2_STAMP(3);
     }
 }
 

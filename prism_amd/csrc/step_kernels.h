@@ -15,10 +15,10 @@ namespace prism {
 // IQN: per weight set (online, target) u,v (H/4 blocks, LayerNorm only) and the stream-packed weights;
 // Q heads: per head and weight set W1 packing and u_h,v_h; per head ||theta_h||^2 (online).
 struct ExtraDims {
-    int use_iqn, n_heads, has_target, head_layers, Hi, Hq, ln, split;
+    int use_iqn, n_heads, has_target, head_layers, Hi, Hq, ln, split, cos_tiles;
 };
 __host__ __device__ inline ExtraDims extra_dims(const IqnArgs &a) {
-    return ExtraDims{a.use_iqn, a.n_heads, a.has_target, a.head_layers, a.Hi, a.Hq, a.ln, a.split};
+    return ExtraDims{a.use_iqn, a.n_heads, a.has_target, a.head_layers, a.Hi, a.Hq, a.ln, a.split, a.cos_tiles};
 }
 __host__ __device__ inline int iqn_pack_blocks_for(int H, int split) { return split ? iqn_pack_split_blocks(H) : iqn_pack_blocks(H); }
 __host__ __device__ inline int q_pack_blocks_for(int H, int split) { return split ? q_pack_split_blocks_per_head(H) : q_pack_blocks_per_head(H); }
@@ -28,13 +28,100 @@ __host__ __device__ inline int front_extra_blocks(const ExtraDims &d) {
     int n = 0;
     if (d.use_iqn) n += sets * ((d.ln ? d.Hi / 4 : 0) + iqn_pack_blocks_for(d.Hi, d.split));
     n += heads * (sets * (q_pack_blocks_for(d.Hq, d.split) + (d.ln ? d.Hq / 4 : 0)) + Q_NORM_PARTS);
+    n += d.cos_tiles;          // (last: one block per IQN forward tile, cos_basis_block)
     return n;
+}
+
+// Quantile samples and cos basis of ONE forward tile (iqn_model.py:90-92), prepared beside the sampling / convolution
+// workgroups of the embed / front launch instead of in the forward tile's prologue -- there the draw (a cold counter word,
+// ten Philox rounds), two cosines a thread, the split into bf16 pieces and two workgroup barriers sat in front of the
+// first matrix instruction of every tile (7 k cycles of a 45 k tile, stamped).  Same expressions, same bits as the tile's own
+// prologue (fwd_kernels.h), which stays for the passes that do not come through here (acting).
+// 256 threads: row m = tid >> 4, basis pairs (tid & 15) and (tid & 15) + 16.
+__device__ __forceinline__ void cos_basis_block(const IqnArgs &a, int x) {
+    const int tid = threadIdx.x;
+    int tile = x, pi = -1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const bool mine = i < a.n_pass && a.pass[i].kind != 1 && a.pass[i].cospk != nullptr;
+        const int nt = mine ? a.pass[i].n_tiles : 0;
+        const bool hit = mine && pi < 0 && tile < nt;
+        pi = hit ? i : pi;
+        tile -= (pi < 0) ? nt : 0;
+    }
+    if (pi < 0) return;
+    // (fields picked with comparisons, not a.pass[pi]: a run-time index into the by-value argument struct moves it to scratch)
+    const float *tau_in = nullptr, *tau_in2 = nullptr;
+    const unsigned int *cpk = nullptr;
+    int T = 1, save = 0, sid0 = 0, kind = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (i == pi) {
+            tau_in = a.pass[i].tau_in; tau_in2 = a.pass[i].tau_in2; cpk = a.pass[i].cospk;
+            T = a.pass[i].T; save = a.pass[i].save; sid0 = a.pass[i].stream_id; kind = a.pass[i].kind;
+        }
+    const int m = tid >> 4, kq = tid & 15, tsh = 31 - __clz(T);
+    int b, t, nx = 0;
+    int64_t srow;
+    if (kind == 0) {
+        const int row = tile * 16 + m;
+        b = min((T & (T - 1)) == 0 ? row >> tsh : row / T, a.B - 1);
+        t = row - b * T;
+        srow = save ? (int64_t)row : -1;
+    } else {
+        const int s = m >> (tsh + 1), j = m & (2 * T - 1);
+        b = tile * (16 >> (tsh + 1)) + s;
+        nx = j >= T;
+        t = j & (T - 1);
+        srow = nx ? -1 : (int64_t)b * T + t;
+    }
+    const float *tin = (kind == 2 && nx) ? tau_in2 : tau_in;
+    const int sid = (kind == 2 && nx) ? 1 : sid0;
+    float tau;
+    if (tin) {
+        tau = tin[min((int64_t)t, (int64_t)T - 1) * a.Bt + b];
+    } else {
+        uint32_t rr[4];
+        Philox ph(a.seed);
+        ph(a.offset + (a.rng ? a.rng[1] : 0ull) + (uint64_t)((int64_t)t * a.Bt + b), 0x54415530ull + (uint64_t)sid, rr);
+        tau = u32_to_unit_float(rr[0]);
+    }
+    unsigned int *blk = const_cast<unsigned int *>(cpk) + (size_t)tile * CP_TILE;
+    if (kq == 0) {
+        if (a.tau_out && t < T) a.tau_out[(int64_t)sid * a.maxT * a.Bt + (int64_t)t * a.Bt + b] = tau;
+        blk[3 * 16 * 32 + m] = __float_as_uint(tau);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int kp = kq + 16 * q, k0 = 2 * kp;
+        const float c0 = cosf((tau * (float)(k0 + 1)) * PI_F), c1 = cosf((tau * (float)(k0 + 2)) * PI_F);
+        if (srow >= 0) {
+            __builtin_nontemporal_store(c0, &a.ws.cosb[srow * K_BASIS + k0]);
+            __builtin_nontemporal_store(c1, &a.ws.cosb[srow * K_BASIS + k0 + 1]);
+        }
+        const unsigned int h = pack_bf16(c0, c1);
+        const float ra = c0 - __uint_as_float(h << 16), rb = c1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned int md = pack_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(md << 16), sb = rb - __uint_as_float(md & 0xffff0000u);
+        blk[(0 * 16 + m) * 32 + kp] = h;
+        blk[(1 * 16 + m) * 32 + kp] = md;
+        blk[(2 * 16 + m) * 32 + kp] = pack_bf16(sa, sb);
+    }
 }
 
 // The TARGET network only changes when it is synchronised: its packed copies and u/v are rebuilt only while
 // ws.ticket[2] ("target set packed") is zero -- the post launch of every update sets it, whoever writes target_params
 // (prism_sync_target's caller, a checkpoint load) clears it.  With ten Q heads that is half of this launch's blocks.
 __device__ __forceinline__ void front_extra_block(const IqnArgs &a, int x, float *s_red) {
+    {
+        ExtraDims d0 = extra_dims(a);
+        d0.cos_tiles = 0;
+        const int n_other = front_extra_blocks(d0);
+        if (x >= n_other) {
+            cos_basis_block(a, x - n_other);
+            return;
+        }
+    }
     const int tid = threadIdx.x;
     const int sets = 1 + (a.has_target ? 1 : 0);
     const bool target_done = a.has_target && a.ws.ticket[2] != 0u;

@@ -39,6 +39,15 @@ rl = np.where(s[:nfw, 38] != 0, s[:nfw, 38], s[:nfw, 36]).astype(np.float64)
 ss, sp = rt_spans(s[:nfw, 32].astype(np.float64), rl)
 print(f"   workgroup total: median {np.median(dur):9.0f}  p95 {np.percentile(dur, 95):9.0f}  max {dur.max():9.0f};  start spread {ss:6.2f} us   "
       f"first start -> last end {sp:6.2f} us")
+if nfw > 256:
+    r0_, r1_ = s[:nfw, 32].astype(np.float64), np.where(s[:nfw, 38] != 0, s[:nfw, 38], s[:nfw, 36]).astype(np.float64)
+    t00 = r0_.min()
+    order = np.argsort(r0_)
+    print("   tile start / end (us, real time) by start order, every 32nd:", [(int(i), round((r0_[i] - t00) / 100, 1), round((r1_[i] - t00) / 100, 1)) for i in order[::32]])
+    for lo_, hi_, nm in ((0, 256, "tiles 0..255"), (256, nfw, f"tiles 256..{nfw - 1}")):
+        ph = [np.median((f[lo_:hi_, k + 1] - f[lo_:hi_, k])[f[lo_:hi_, k + 1] != 0]) if (f[lo_:hi_, k + 1] != 0).any() else 0 for k in range(6)]
+        rs0 = s[lo_:hi_, 32].astype(np.float64)
+        print(f"   {nm}: phases {[int(x) for x in ph]} total med {int(np.median(dur[lo_:hi_]))}; starts {(rs0.min() - s[:nfw, 32].min()) / 100:.2f}..{(rs0.max() - s[:nfw, 32].min()) / 100:.2f} us")
 nb = int((s[:, 8] != 0).sum())
 b = s[:nb, 8:13].astype(np.float64)
 print(f"bwd ({nb} workgroups):")

@@ -1,7 +1,7 @@
-"""Diagnostic: phase stamps of qh_bwd2_kernel (GPU box; PRISM_DBG=8).  Stamps land in the shared buffer; the post kernel
+"""Diagnostic: phase stamps of qh_bwd2_kernel (GPU box; PRISM_DBG=32).  Stamps land in the shared buffer; the post kernel
 overwrites some slots afterwards, so the kernel's own slots 0..3 / 32..35 are read (post uses 7.. / 13..)."""
 import os, sys, contextlib, io
-os.environ["PRISM_DBG"] = "8"
+os.environ["PRISM_DBG"] = "32"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from prism_amd.config import baseline_config
