@@ -798,7 +798,17 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     __shared__ __attribute__((aligned(16))) char s_pool[POOL];
     __shared__ float s_red[64];
     PRISM_STAMP(13);
-    if (wb.enabled && (int)blockIdx.x == wb.block) {
+    // Which role: the launch's workgroups start in index order and, when they are not all resident at once (c4: 640 of
+    // them, 2.5 rounds of the CUs), the ones that start last had better be short.  The longest roles sit at the END of the
+    // role order (the Q heads' small-tensor folds, the priority writeback): the split form rotates them to the front.
+    // (The fused tail keeps the identity: its launch is resident at once, and its share / rank arithmetic is by index.)
+    int bid = blockIdx.x;
+    if constexpr (!TAIL) {
+        const int rot = (a.head_layers == 2 ? a.n_heads * post_small_blocks(a.Hq) : 0) + (wb.enabled ? 1 : 0);
+        const int nb = (int)gridDim.x;
+        if (rot < nb) bid = bid < rot ? nb - rot + bid : bid - rot;
+    }
+    if (wb.enabled && bid == wb.block) {
         // (models with both parts: td = dl / 2 + ql / 2 is combined HERE from the two losses -- out_td is written by another
         // block of this launch, the Q loss no longer reads the IQN loss's output: the two loss kernels are one launch)
         const bool both = a.use_iqn && a.n_heads > 0;
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const bool dqn1 = a.head_layers == 1 && a.n_heads;
     const int n_conv = dqn1 ? dqn1_conv_blocks(C) : (a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB);
-    int blk = blockIdx.x;
+    int blk = bid;
     float sq = 0.f;
     float4 g_own = make_float4(0.f, 0.f, 0.f, 0.f);     // (fused tail) the slab sum of this thread, kept for its Adam update
     bool far_all = false;       // every store of this role that another workgroup reads behind the barrier was a far_store
@@ -888,7 +898,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         PRISM_STAMP(21);
     } else if (blk < n_conv) {
         __shared__ int s_last;
-        conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
+        conv_bwd_partial_block<!TAIL>(a, blk, reinterpret_cast<float *>(s_pool));
         PRISM_STAMP(20);
         // publish, then let the last arriver fold all partial rows (the placement-independent hand-off of the
         // CDNA guide): EVERY storing wave drains its stores (a barrier alone only proves they were issued),
@@ -1041,8 +1051,8 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     }
     const float t = block_sum_1024(sq, s_red);
     // (agent scope: written through to where the other XCDs' agent-scope loads look for it, whatever release follows)
-    if (tid == 0) __hip_atomic_store(a.ws.normpart + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && tid == 0 && a.has_target) a.ws.ticket[2] = 1u;      // the front / embed launch of this update packed the target set
+    if (tid == 0) __hip_atomic_store(a.ws.normpart + bid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bid == 0 && tid == 0 && a.has_target) a.ws.ticket[2] = 1u;      // the front / embed launch of this update packed the target set
     PRISM_STAMP(14);
     if constexpr (TAIL) {
         const int n_role = wb.enabled ? (int)gridDim.x - 1 : (int)gridDim.x;
