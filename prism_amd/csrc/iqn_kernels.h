@@ -1106,88 +1106,30 @@ constexpr LdsRegion CV_OBS{0, CONV_SPB * 1000, LDS_ALWAYS}, CV_DC{CONV_SPB * 100
 constexpr LdsRegion CV_PAR{CONV_SPB * (1000 + 16 * 65), CONV_SPB * 16 * 10 * 3 * 3, LDS_ALWAYS};     // (c, ci, dy) x 3 per sample, C <= 10
 constexpr LdsRegion CV_REGIONS[] = {CV_OBS, CV_DC, CV_PAR};
 static_assert(lds_layout_ok(CV_REGIONS, CONV_LDS_FLOATS), "conv backward block: LDS regions overlap");
-// WIDE: the staging with every operand requested up front (the split post launch, whose conv workgroups are its critical
-// path); the fused tail's instantiations keep the compact rolled form -- the unrolled one costs them instructions they never
-// run in the configurations that matter (c3: +0.4 us on the tail launch, same-box A/B)
-template <bool WIDE>
+// (Measured and not kept: the staging with every operand requested up front -- one round of loads instead of three, -0.8 us
+// on c4's post launch once its long roles start first, but with it in the library c3's front launch runs 0.5 us longer,
+// same-box A/B, four alternations; the cause was not found.)
 __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *lds) {
     float *s_obs = lds + CV_OBS.off, *s_dc = lds + CV_DC.off, *s_par = lds + CV_PAR.off;
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const int b0 = cb * CONV_SPB, ns = min(CONV_SPB, B - b0);
-    if constexpr (WIDE) {
-        // every operand of the staging requested before the first LDS store (as two loops of two unrolled trips each it was
-        // three dependent memory round trips: 13 k cycles of a 28 k workgroup).  Head slots go two a round: the bf16 path's
-        // Q-ensemble backward leaves two, so one round; written out for sixteen slots the staging cost every instantiation
-        // of the post kernel 2 k instructions.
-        static_assert(CONV_SPB * 1000 <= 4 * 1024 && CONV_SPB * E_DIM == 4 * 1024, "staging: four trips of 1024 threads");
-        float ov[4], dv[4], ev[4], d0[4], d1[4];
-        const int slots = a.q_de_slots;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 1024 * j;
-            const int so = i / (100 * C), o = i - so * 100 * C;
-            ov[j] = i < ns * 100 * C ? a.obs[(int64_t)(b0 + so) * 100 * C + o] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 1024 * j, sd = i >> 10, n = i & 1023;
-            const bool ok = sd < ns;
-            const int64_t o = (int64_t)(b0 + (ok ? sd : 0)) * E_DIM + n;
-            dv[j] = (ok && a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
-            ev[j] = ok ? a.ws.e_cur[o] : 0.f;
-            d0[j] = (ok && 0 < slots) ? a.ws.de_q[o] : 0.f;
-            d1[j] = (ok && 1 < slots) ? a.ws.de_q[(size_t)B * E_DIM + o] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 1024 * j;
-            const int so = i / (100 * C), o = i - so * 100 * C;
-            if (i < ns * 100 * C) s_obs[so * 1000 + o] = ov[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (0 < slots) dv[j] += d0[j];                  // slots in fixed order
-            if (1 < slots) dv[j] += d1[j];
-        }
-        for (int hd = 2; hd < slots; hd += 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = tid + 1024 * j, sd = i >> 10, n = i & 1023;
-                const bool ok = sd < ns;
-                const int64_t o = (int64_t)(b0 + (ok ? sd : 0)) * E_DIM + n;
-                d0[j] = ok ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
-                d1[j] = (ok && hd + 1 < slots) ? a.ws.de_q[(size_t)(hd + 1) * B * E_DIM + o] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dv[j] += d0[j];
-                if (hd + 1 < slots) dv[j] += d1[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + 1024 * j, sd = i >> 10, n = i & 1023;
-            if (sd < ns) s_dc[sd * (16 * 65) + (n >> 6) * 65 + (n & 63)] = ev[j] > 0.f ? dv[j] : 0.f;
-        }
-    } else {
 #pragma unroll 2
-        for (int i = tid; i < ns * 100 * C; i += 1024) {
-            const int s = i / (100 * C), o = i - s * 100 * C;
-            s_obs[s * 1000 + o] = a.obs[(int64_t)(b0 + s) * 100 * C + o];
-        }
+    for (int i = tid; i < ns * 100 * C; i += 1024) {
+        const int s = i / (100 * C), o = i - s * 100 * C;
+        s_obs[s * 1000 + o] = a.obs[(int64_t)(b0 + s) * 100 * C + o];
+    }
 #pragma unroll 2
-        for (int i = tid; i < ns * E_DIM; i += 1024) {
-            const int s = i >> 10, n = i & 1023;
-            const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
-            float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
-            float dh[16];                                    // every head's value requested before the first add
+    for (int i = tid; i < ns * E_DIM; i += 1024) {
+        const int s = i >> 10, n = i & 1023;
+        const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
+        float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
+        float dh[16];                                    // every head's value requested before the first add
 #pragma unroll
-            for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.q_de_slots ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
+        for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.q_de_slots ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
 #pragma unroll
-            for (int hd = 0; hd < 16; ++hd)
-                if (hd < a.q_de_slots) d += dh[hd];          // slots in fixed order
-            s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
-        }
+        for (int hd = 0; hd < 16; ++hd)
+            if (hd < a.q_de_slots) d += dh[hd];          // slots in fixed order
+        s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
     }
     __syncthreads();
     PRISM_STAMP(22);

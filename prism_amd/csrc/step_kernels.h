@@ -898,7 +898,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         PRISM_STAMP(21);
     } else if (blk < n_conv) {
         __shared__ int s_last;
-        conv_bwd_partial_block<!TAIL>(a, blk, reinterpret_cast<float *>(s_pool));
+        conv_bwd_partial_block(a, blk, reinterpret_cast<float *>(s_pool));
         PRISM_STAMP(20);
         // publish, then let the last arriver fold all partial rows (the placement-independent hand-off of the
         // CDNA guide): EVERY storing wave drains its stores (a barrier alone only proves they were issued),
