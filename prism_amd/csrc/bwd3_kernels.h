@@ -26,6 +26,13 @@
 #include "qbwd2_kernels.h"
 
 namespace prism {
+// (diagnostic stamp of the helper team: its first thread)
+#define BW3_HSTAMP(k)                                                                      \
+    do {                                                                                   \
+        if ((a.dbg & 8) && threadIdx.x == 256)                                             \
+            a.stamps[(size_t)(2048 + blockIdx.x) * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 
 constexpr int BW3_H = 128, BW3_RB = 32;            // width; rows per block
 constexpr int BW3_RC = 16;                        // row chunks (gradient slabs)
@@ -150,20 +157,27 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
             }                                                                                                       \
         }                                                                                                           \
     } while (0)
+        BW3_HSTAMP(9);
         request(0);
         // (the observation rows behind the first block's operands: memory operations of a wave return in order)
+        // (idx / (10 C) by multiplication: idx < 1024, 10 C <= 100 -- sixteen run-time divisions here were 3 k cycles in front of
+        // the first block's staging, i.e. of every wave's first barrier)
+        const unsigned int rdiv = (1u << 20) / (unsigned int)(10 * C) + 1u;      // exact for idx < 1024, 10 C <= 100 (checked offline)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = lane + 64 * i;
             if (idx < ws_n * 10 * C) {
-                const int sm = idx / (10 * C), o4 = idx - sm * 10 * C;
+                const int sm = (int)(((unsigned int)idx * rdiv) >> 20), o4 = idx - sm * 10 * C;
                 const float *src = a.obs + ((int64_t)(ws_lo + sm) * 100 + y0 * 10) * C + 4 * o4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(s_obs + 256 * i), 16, 0, 0);
             }
         }
+        BW3_HSTAMP(10);
         stage(smem);
+        BW3_HSTAMP(11);
         lds_barrier();                                              // (1) block 0 is parked
+        BW3_HSTAMP(12);
         for (int blk = 0; blk < nblk; ++blk) {
             if (n_mine && blk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's observation rows have landed
             if (blk + 1 < nblk) request(blk + 1);
@@ -221,6 +235,7 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
         for (int j = 0; j < 8; ++j) wv[j] = P[a.off.iqn_w1 + (int64_t)(32 * kb + 8 * g + j) * E_DIM + n];
         w1p[kb] = split_bf16x3(wv);
     }
+    PRISM_STAMP2(13);
     const float g1 = LN ? P[a.off.iqn_ln1_g + n] : 1.f, be1 = LN ? P[a.off.iqn_ln1_b + n] : 0.f;
     const __amdgpu_buffer_rsrc_t rs_ph = __builtin_amdgcn_make_buffer_rsrc(a.ws.phis, 0, ((R + 15) / 16) * 16 * E_DIM * 4, 0x00020000);
     const int vo_ph = (4 * g * 16 + li) * 4;
@@ -254,7 +269,9 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
     };
     RowData D;
     load_rows(D, 0);
+    PRISM_STAMP2(14);
     lds_barrier();                                                  // (1)
+    PRISM_STAMP2(15);
     PRISM_STAMP(9);
     for (int blk = 0; blk < nblk; ++blk) {
         const char *cur = smem + (blk & 1) * BW3_BUF;

@@ -62,6 +62,11 @@ rl = np.where(s[:nb, 58] != 0, s[:nb, 58], s[:nb, 44]).astype(np.float64)
 ss, sp = rt_spans(s[:nb, 40].astype(np.float64), rl)
 print(f"   workgroup total: median {np.median(bd):9.0f}  p95 {np.percentile(bd, 95):9.0f}  max {bd.max():9.0f};  start spread {ss:6.2f} us   "
       f"first start -> last end {sp:6.2f} us")
+b2 = s[2048:2048 + nb].astype(np.float64)
+if b2[:, 13].any():
+    e0 = s[:nb, 8].astype(np.float64)
+    print("   bwd3 prologue (ticks after the entry stamp): compute W1 split done %d, rows requested %d, past barrier %d | helper: start %d, block 0 arrived %d, staged %d, past barrier %d"
+          % tuple(int(np.median(b2[:, k] - e0)) for k in (13, 14, 15, 9, 10, 11, 12)))
 bt = s[:nb, [12, 26]].astype(np.float64)
 if bt[:, 1].any(): print("   conv tail:", int(np.median(bt[:, 1] - bt[:, 0])))
 
