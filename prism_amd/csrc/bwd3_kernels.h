@@ -159,7 +159,13 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
     } while (0)
         BW3_HSTAMP(9);
         request(0);
-        // (the observation rows behind the first block's operands: memory operations of a wave return in order)
+        BW3_HSTAMP(10);
+        stage(smem);
+        BW3_HSTAMP(11);
+        lds_barrier();                                              // (1) block 0 is parked
+        BW3_HSTAMP(12);
+        // the observation rows are asked for only now: sixty-four more wave-loads in front of the first barrier kept the
+        // address unit busy while every wave of the workgroup waited for block 0 (they are first needed at block 1's taps)
         // (idx / (10 C) by multiplication: idx < 1024, 10 C <= 100 -- sixteen run-time divisions here were 3 k cycles in front of
         // the first block's staging, i.e. of every wave's first barrier)
         const unsigned int rdiv = (1u << 20) / (unsigned int)(10 * C) + 1u;      // exact for idx < 1024, 10 C <= 100 (checked offline)
@@ -173,11 +179,6 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
                                                  (__attribute__((address_space(3))) void *)(s_obs + 256 * i), 16, 0, 0);
             }
         }
-        BW3_HSTAMP(10);
-        stage(smem);
-        BW3_HSTAMP(11);
-        lds_barrier();                                              // (1) block 0 is parked
-        BW3_HSTAMP(12);
         for (int blk = 0; blk < nblk; ++blk) {
             if (n_mine && blk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's observation rows have landed
             if (blk + 1 < nblk) request(blk + 1);
