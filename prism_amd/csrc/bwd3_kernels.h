@@ -184,7 +184,10 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
             if (blk + 1 < nblk) request(blk + 1);
             if (n_mine && blk >= 1) BW3_TAPS(blk - 1);
             if (blk + 1 < nblk) stage(smem + ((blk + 1) & 1) * BW3_BUF);
+            if (blk == 3) BW3_HSTAMP(20);
             lds_barrier();                                          // (2 + blk)
+            if (blk == 3) BW3_HSTAMP(21);
+            if (blk == 2) BW3_HSTAMP(19);
         }
         if (n_mine) {
             if (nblk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -279,20 +282,28 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
         const bool more = blk + 1 < nblk;
         const char *PD = cur, *CS = cur + 3 * BW3_P;
         float xs8[8], dp8[8];
+        u32x4 xa[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int r0 = row0 + blk * BW3_RB + 16 * t;
             // dX[m = 4g + r][n] = sum_h dpre1[m][h] W1[h][n]: A = the image's rows (eight consecutive hidden units a lane)
             f32x4 adx = {0.f, 0.f, 0.f, 0.f};
-            u32x4 xa[4][3];
+            // (K blocks walked one ahead, like the operand groups below; the first block of tile 1 is asked for before
+            // tile 0's element-wise work)
+            auto xrd = [&](int tt, int kb, u32x4 (&o)[3]) __attribute__((always_inline)) {
+                const char *ar = PD + (16 * tt + li) * BW3_PROW + 64 * kb + 16 * g;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) o[pl] = *reinterpret_cast<const u32x4 *>(ar + pl * BW3_P);
+            };
+            if (t == 0) xrd(0, 0, xa[0]);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                const char *ar = PD + (16 * t + li) * BW3_PROW + 64 * kb + 16 * g;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xa[kb][pl] = *reinterpret_cast<const u32x4 *>(ar + pl * BW3_P);
+                if (kb + 1 < 4) xrd(t, kb + 1, xa[(kb + 1) & 1]);
+                else if (t == 0) xrd(1, 0, xa[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                adx = mfma_split(xa[kb & 1][0], xa[kb & 1][1], xa[kb & 1][2], w1p[kb], adx);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) adx = mfma_split(xa[kb][0], xa[kb][1], xa[kb][2], w1p[kb], adx);
             // element-wise backward of the tile's rows 4g + r, column n (as iqn_bwd_kernel)
             const float ev = D.ev[t];
             float dep = 0.f;
@@ -336,24 +347,43 @@ __global__ __launch_bounds__(512) void iqn_bwd3_kernel(IqnArgs a) {
         if (more) load_rows(D, blk + 1);          // (this block's row data is consumed)
         const Split3 X = split_bf16x3(xs8), DP = split_bf16x3(dp8);
         // dWphi[n][k] += sum_m dphi[m][n] cos[m][k]: A = dphi (own registers), B = cos by transposed reads
-        Split3 cb[4];
-        u32x4 wa[NHT][3];
+        // dW1[h][n]   += sum_m dpre1[m][h] x[m][n]: A = dpre1 by transposed reads of the same image, B = x (own registers)
+        // Twelve operand groups (4 cos column blocks, 8 hidden tiles), each three transposed piece reads + six MFMAs, walked
+        // ONE GROUP AHEAD: the reads of group q + 1 are in flight while the MFMAs of group q issue.  (All 72 reads first and
+        // then all 72 MFMAs -- what the straight-line form compiled to -- left this one wave per SIMD waiting for LDS: 5.2 k
+        // cycles a block for 1.9 k of matrix work, with the helper team idle 70 % of the time.)
+        auto grp = [&](int q, u32x4 (&o)[3]) __attribute__((always_inline)) {
+            if (q < 4) {
+                o[0] = bw3_tr_rows(CS, BW3_CROW, 16 * q, lane);
+                o[1] = bw3_tr_rows(CS + BW3_C, BW3_CROW, 16 * q, lane);
+                o[2] = bw3_tr_rows(CS + 2 * BW3_C, BW3_CROW, 16 * q, lane);
+            } else {
+                o[0] = bw3_tr_rows(PD, BW3_PROW, 16 * (q - 4), lane);
+                o[1] = bw3_tr_rows(PD + BW3_P, BW3_PROW, 16 * (q - 4), lane);
+                o[2] = bw3_tr_rows(PD + 2 * BW3_P, BW3_PROW, 16 * (q - 4), lane);
+            }
+        };
+        u32x4 og[2][3];
+        grp(0, og[0]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            cb[c].hi = bw3_tr_rows(CS, BW3_CROW, 16 * c, lane);
-            cb[c].mid = bw3_tr_rows(CS + BW3_C, BW3_CROW, 16 * c, lane);
-            cb[c].lo = bw3_tr_rows(CS + 2 * BW3_C, BW3_CROW, 16 * c, lane);
+        for (int q = 0; q < 4 + NHT; ++q) {
+            if (q + 1 < 4 + NHT) grp(q + 1, og[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 4) {
+                Split3 cbq;
+                cbq.hi = og[q & 1][0];
+                cbq.mid = og[q & 1][1];
+                cbq.lo = og[q & 1][2];
+                accWphi[q] = mfma_split(DP.hi, DP.mid, DP.lo, cbq, accWphi[q]);
+            } else {
+                accW1[q - 4] = mfma_split(og[q & 1][0], og[q & 1][1], og[q & 1][2], X, accW1[q - 4]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wa[ht][pl] = bw3_tr_rows(PD + pl * BW3_P, BW3_PROW, 16 * ht, lane);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) accWphi[c] = mfma_split(DP.hi, DP.mid, DP.lo, cb[c], accWphi[c]);
-        // dW1[h][n] += sum_m dpre1[m][h] x[m][n]: A = dpre1 by transposed reads of the same image, B = x (own registers)
-#pragma unroll
-        for (int ht = 0; ht < NHT; ++ht) accW1[ht] = mfma_split(wa[ht][0], wa[ht][1], wa[ht][2], X, accW1[ht]);
+        if (blk == 3) PRISM_STAMP2(17);
         lds_barrier();                                              // (2 + blk)
+        if (blk == 3) PRISM_STAMP2(18);
+        if (blk == 2) PRISM_STAMP2(16);
     }
     PRISM_STAMP(10);
     // ---- this wave's part of the chunk's slab: nobody else holds these columns

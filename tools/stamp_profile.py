@@ -67,6 +67,9 @@ if b2[:, 13].any():
     e0 = s[:nb, 8].astype(np.float64)
     print("   bwd3 prologue (ticks after the entry stamp): compute W1 split done %d, rows requested %d, past barrier %d | helper: start %d, block 0 arrived %d, staged %d, past barrier %d"
           % tuple(int(np.median(b2[:, k] - e0)) for k in (13, 14, 15, 9, 10, 11, 12)))
+if b2[:, 17].any():
+    print("   bwd3 block 3 (ticks): compute work %d, wait at the barrier %d | helper work %d, wait %d"
+          % tuple(int(np.median(b2[:, x] - b2[:, y])) for x, y in ((17, 16), (18, 17), (20, 19), (21, 20))))
 bt = s[:nb, [12, 26]].astype(np.float64)
 if bt[:, 1].any(): print("   conv tail:", int(np.median(bt[:, 1] - bt[:, 0])))
 
