@@ -32,6 +32,7 @@ def check(tag):
         assert float(t[1, 0]) > 0 and float(t[1, 1]) > 0
     assert bool(torch.isfinite(ag.flat).all()), f"{tag}: non-finite parameters"
     assert int(buf.status.item()) == 0, f"{tag}: sticky status {int(buf.status.item())}"
+    ag.check_status()          # the fused tail's grid barrier never timed out (workspace status word)
 
 
 t0 = time.time()
