@@ -34,6 +34,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert n in N.SIGNATURES, f"{n} has no ctypes signature in prism_amd/_native.py"
     assert set(N.SIGNATURES) == set(names)
     assert lib.prism_abi_version() == 2
+    # (documentation drift guard: DESIGN.md quotes the number of entry points)
+    assert f"({len(names)} entry points)" in open(os.path.join(H.ROOT, "DESIGN.md")).read()
 
 
 def test_struct_layouts_match_header():
