@@ -190,7 +190,10 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i]; 2 = the metric's config")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0: enough for ~2000 steps)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed blocks of --steps steps (0: as many as fill --min-seconds of timed GPU work, at least 5)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="with --repeats 0: total duration of the timed blocks (the GPU is busy for this long back to back)")
     ap.add_argument("--profile-steps", type=int, default=128, help="eager, HIP-event instrumented steps after the timing")
     args = ap.parse_args()
 
@@ -268,22 +271,34 @@ def main():
     for i in range(N.N_KERNEL_IDS):
         ms[i], cnt[i] = 0.0, 0
     # timed region: `repeats` blocks of EXACTLY `steps` steps each, every block bracketed by barrier + synchronize;
-    # the reported rate is the median block (a 20-step block is 2 ms: one block alone is mostly noise)
-    repeats = args.repeats if args.repeats > 0 else min(200, max(5, -(-2000 // max(1, args.steps))))
-    blocks, own_blocks = [], []
-    for _ in range(repeats):
+    # the reported rate is the median block (a 20-step block is 2 ms: one block alone is mostly noise).  With --repeats 0
+    # the number of blocks is sized from the first one so that the timed blocks add up to >= --min-seconds of back-to-back
+    # GPU work (the same count on every rank: it comes from the MAX-over-ranks time of block 0)
+    def timed_block():
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
             learner.step()
         sync()
-        dt = time.perf_counter() - t0
-        own_blocks.append(dt)
+        own = time.perf_counter() - t0
+        dt = own
         if world > 1:
-            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            t = torch.tensor([own], device="cpu" if rehearsal else dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             dt = float(t.item())
+        return own, dt
+
+    own0, dt0 = timed_block()
+    repeats = args.repeats if args.repeats > 0 else int(min(20000, max(5, -(-args.min_seconds // max(dt0, 1e-6)))))
+    blocks, own_blocks = [dt0], [own0]
+    for _ in range(repeats - 1):
+        own, dt = timed_block()
+        own_blocks.append(own)
         blocks.append(dt)
+    # a step that hit an abandoned grid barrier or a collective time-out applied no (or half an) update: such a run has
+    # no rate to report (sticky status words of the learner workspace, the replay and the direct collective)
+    agent.check_status()
+    buf.check_status()
     elapsed = float(np.median(blocks))
     dp_info = None
     if world > 1:
@@ -312,6 +327,12 @@ def main():
             if cnt[i]:
                 kern[L.prism_profile_kernel_name(i).decode()] = ms[i] / cnt[i] * 1e3     # us per launch
         fl = {k: v for k, v in kernel_flops(cfg, cfg.batch_size).items() if v}
+        # the instrumentation names launches by role; the IQN backward that RUNS at width 128 on the bf16 pipe is
+        # iqn_bwd3_kernel (bwd3_kernels.h), elsewhere iqn_bwd_kernel
+        bwd_name = "iqn_bwd3_kernel" if (gemm_mode == "bf16x3" and cfg.iqn_quantile_model_feature_dim == 128) else "iqn_bwd_kernel"
+        for d_ in (kern, fl):
+            if "iqn_bwd_kernel" in d_:
+                d_[bwd_name] = d_.pop("iqn_bwd_kernel")
         P = agent.flat.numel()
         P_tgt = P if cfg.use_target_network else 0
         levels = int(np.log2(buf.tree_capacity))
@@ -332,14 +353,26 @@ def main():
             slab = (1024 * 64 + 1024 + ln + Hi * 1024) * (8 if Hi == 128 else 4) if cfg.use_iqn else 0
             qslab = n_heads * (ln + Hq * 1024)
             kbytes["iqn_post_kernel"] = 4 * (slab + qslab) + 4 * P
-        traffic_all, traffic_src = {}, None
+        traffic_all, traffic_src, rocprof_us, rocprof_tag = {}, None, {}, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic_all = tj.get(f"configs{args.config}", {})
-            traffic_src = {"file": "profiles/traffic.json", "tag": tj.get("_meta", {}).get(f"configs{args.config}", "r02e"),
-                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of an earlier run of this command (not measured "
+            rocprof_tag = tj.get("_meta", {}).get(f"configs{args.config}", "r02e")
+            traffic_src = {"file": "profiles/traffic.json", "tag": rocprof_tag, "measured_in_run": False,
+                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of an earlier run of this command (NOT measured "
                                    "in this run): (2*FETCH + WRITE)*1024 per launch"}
+            # the rocprofv3 --kernel-trace --stats averages committed with that tag (no launch boundary in them)
+            spath = os.path.join(ROOT, "profiles", f"{rocprof_tag}_configs{args.config}_kernel_stats.csv")
+            if os.path.exists(spath):
+                import csv
+                for r in csv.DictReader(open(spath)):
+                    try:
+                        if "prism::" in r["Name"] and int(r["Calls"]) > 100:
+                            rocprof_us[r["Name"].split("(")[0].replace("void ", "").replace("prism::", "").split("<")[0]] = \
+                                float(r["AverageNs"]) / 1e3
+                    except (KeyError, ValueError, TypeError):
+                        pass
         roof = None
         if kern:
             mf = [k for k in fl if kern.get(k)]
@@ -349,6 +382,13 @@ def main():
                 roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                         "traffic": traffic_all.get(dom), "flops_per_launch": fl[dom]}
+                if rocprof_us.get(dom):
+                    # the same kernel by rocprofv3's own duration (committed profile of an earlier run of this command: no
+                    # launch boundary inside): printed beside the event-timed figure so the two cannot drift apart silently
+                    roof["frac_rocprof"] = round(fl[dom] / (rocprof_us[dom] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                    roof["rocprof"] = {"tag": rocprof_tag, "us_per_launch": round(rocprof_us[dom], 3),
+                                       "file": f"profiles/{rocprof_tag}_configs{args.config}_kernel_stats.csv",
+                                       "measured_in_run": False}
                 if gemm_mode == "bf16x3":
                     # the same fp32-accurate products, executed as six bf16 piece products each on the bf16 pipe
                     roof["pipe"] = {"gemm_mode": "bf16x3", "executed_TFLOPs": round(6 * ach, 1), "bf16_dense_peak": BF16_MFMA_PEAK_TFLOPS,
@@ -391,8 +431,10 @@ def main():
                "value_note": "value = grad steps of all replicas per second (per_replica_steps_per_s x n_gpus; every replica "
                              "steps on its own batch of `batch_per_gpu`); SURVEY 8d's per-replica step rate is per_replica_steps_per_s",
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 5),
-               "repeats": repeats, "timing": "median of `repeats` blocks of `steps` steps; min/max block ms_per_step: "
+               "repeats": repeats, "timed_seconds": round(float(sum(blocks)), 3),
+               "timing": "median of `repeats` blocks of `steps` steps; min/max block ms_per_step: "
                f"{min(blocks) / args.steps * 1e3:.5f}/{max(blocks) / args.steps * 1e3:.5f}",
+               "status": "ok (sticky status words of learner workspace, replay and collective read after the timed blocks)",
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                "dtype_note": f"fp32 operands, fp32 accumulation, fp32-accurate results (gemm_mode {gemm_mode}: "
                              + ("each product as six bf16 piece products on the bf16 matrix pipe" if gemm_mode == "bf16x3" else "fp32 MFMA") + ")",

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PRISM_ABI_VERSION 2
+#define PRISM_ABI_VERSION 3
 
 #define PRISM_OK 0
 #define PRISM_ERR_INVALID (-1)     /* bad argument / shape the kernels do not cover          */
@@ -46,6 +46,7 @@ extern "C" {
 /* device status word bits (prism_replay_desc.status) */
 #define PRISM_WS_STATUS_WORD 7             /* index of the sticky status word in prism_learner_desc.workspace (uint32) */
 #define PRISM_WS_STATUS_BARRIER_TIMEOUT 1u
+#define PRISM_WS_STATUS_COLLECTIVE_TIMEOUT 2u /* a direct all-reduce wait gave up (prism_direct_desc.poison): clip + Adam are skipped */
 #define PRISM_STATUS_NONPOSITIVE_PSUM 1
 #define PRISM_STATUS_NONPOSITIVE_PMIN 2
 
@@ -255,6 +256,11 @@ typedef struct prism_learner_desc {
                                  barrier (PRISM_WS_STATUS_BARRIER_TIMEOUT): the step that set it is incomplete     */
     size_t workspace_bytes;
     prism_adam_hyper hyper;
+    /* Optional: uint32[4] in pinned, device-mapped HOST memory (hipHostMalloc; NULL = none), zeroed by the caller.  When
+     * the library raises sticky bit k of the workspace's status word it also stores 1 into word k here (a plain
+     * system-scope store: no PCIe atomics needed), so the host can poll for an abandoned barrier / collective on every
+     * step WITHOUT synchronising with the device (the workspace word itself costs a device-to-host copy to read). */
+    uint32_t *host_status;
 } prism_learner_desc;
 
 /* host: bytes of scratch prism_learner_fwd_bwd needs for (dims, batch). 0 on unsupported dims. */
@@ -343,18 +349,56 @@ int prism_sync_target(float *target_params, const float *params, int64_t n_param
  * the all-gather, and finished the all-gather before anyone overwrites its buffer.  use_flags = 0: the CALLER provides
  * these three barriers (the only legal form when ranks share a device); use_flags = 1 (one device per rank): one-workgroup
  * kernels signal and poll the flag arrays on the stream (phase numbers come from a counter in the flag array itself, so the
- * calls may be captured into a hipGraph and replayed).  A wait that is not through after 2 s sets
- * flags[rank][PRISM_MAX_PEERS] and falls through.
+ * calls may be captured into a hipGraph and replayed).
+ *
+ * Memory types (every word another DEVICE reads or writes while a kernel runs):
+ *   flags[s]  MUST be fine-grained / uncached device memory -- prism_direct_flags_alloc() -- not an ordinary hipMalloc
+ *             (coarse-grained) allocation: a store from a peer into coarse-grained memory is only guaranteed visible at
+ *             kernel boundaries, a kernel polling it may spin on a stale L2 line.  (RCCL keeps its flags the same way.)
+ *   bufs[s]   ordinary (coarse-grained) device memory: written by kernels that END before the flag announcing them is
+ *             stored (the end of a kernel writes its L2 back at system scope), read by kernels that START after the wait
+ *             kernel has ended (the start of a kernel invalidates).  No kernel ever reads a peer's gradient word that is
+ *             written while it runs.
+ * Failure: a wait that is not through after `wait_seconds` (0 = 30 s; RCCL would wait for ever, a rank that saves a
+ * checkpoint or captures a graph can stall for seconds) gives up: it sets flags[rank][PRISM_MAX_PEERS] (sticky), ORs
+ * PRISM_WS_STATUS_COLLECTIVE_TIMEOUT into *poison and into *host_status when given, and every later kernel of the
+ * collective returns at once, as do prism_step_back / prism_learner_clip_adam of a learner whose workspace status word is
+ * `poison`: a timed-out step applies NO update (never a partial sum) and the host sees the bit at its next poll.
  * ------------------------------------------------------------------------------------------ */
 #define PRISM_MAX_PEERS 8
+#define PRISM_DIRECT_FLAG_WORDS (PRISM_MAX_PEERS + 2)
+#define PRISM_IPC_HANDLE_BYTES 64
 typedef struct prism_direct_desc {
     int32_t world, rank;
     float *bufs[PRISM_MAX_PEERS];
     uint32_t *flags[PRISM_MAX_PEERS];
     int64_t n;             /* floats */
+    uint32_t *poison;      /* optional device word (the learner workspace's status word): see Failure above */
+    uint32_t *host_status; /* optional pinned, device-mapped host words [4]: see prism_learner_desc.host_status */
+    double wait_seconds;   /* bound of one flag wait; 0 = 30 s */
 } prism_direct_desc;
 int prism_direct_reduce_scatter(const prism_direct_desc *d, int32_t use_flags, prism_stream_t stream);
 int prism_direct_all_gather(const prism_direct_desc *d, int32_t use_flags, prism_stream_t stream);
+/* One synchronisation point of the protocol as its own launch: phase 1 (gradients written), 2 (slices reduced) or 3
+ * (slices gathered; its wait advances the all-reduce count), what = 1 announce to the peers, 2 wait for them, 3 both
+ * (what use_flags = 1 enqueues).  For callers that pace the phases from the host -- announce, host barrier, wait, the
+ * use_flags = 0 kernel -- e.g. ranks that SHARE a device, where a kernel that spins would keep the peer it waits for
+ * off the device: the flag addressing and the phase arithmetic run exactly as on the step's path. */
+int prism_direct_phase(const prism_direct_desc *d, int32_t phase, int32_t what, prism_stream_t stream);
+
+/* host, synchronous (set-up time, never on the step's path).  The flag array of one rank: PRISM_DIRECT_FLAG_WORDS uint32
+ * of UNCACHED (fine-grained) device memory on the current device, zeroed, plus its inter-process handle
+ * (hipIpcGetMemHandle; PRISM_IPC_HANDLE_BYTES bytes the host ships to the peers however it likes). */
+int prism_direct_flags_alloc(uint32_t **flags_out, void *ipc_handle_out);
+int prism_direct_flags_free(uint32_t *flags);
+/* map a peer's flag array into this process (hipIpcOpenMemHandle) / unmap it */
+int prism_direct_flags_open(const void *ipc_handle, uint32_t **flags_out);
+int prism_direct_flags_close(uint32_t *flags);
+/* hipDeviceEnablePeerAccess(peer_device) from the current device, explicitly (idempotent; PRISM_ERR_HIP when the two
+ * devices have no peer path) -- a mapped peer buffer is only dereferenceable after this. */
+int prism_direct_enable_peer(int32_t peer_device);
+/* copy the PRISM_DIRECT_FLAG_WORDS words of the own flag array to the host (synchronises with `stream`) */
+int prism_direct_flags_read(const uint32_t *flags, uint32_t *host_out, prism_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optional per-kernel timing with HIP events on the launch stream (used by bench.py for the

@@ -147,6 +147,36 @@ void oracle_per_sample(const seg_tree *sum_t, const seg_tree *min_t, int64_t len
 }
 
 /*
+ * Version variants of PrioritizedSampler.sample in torchrl's history (the reference pins no version, so both are
+ * restated and tests/test_oracle_replay.py states what each one changes):
+ *   weight_form 0  torch.pow(p / p_min, -beta) on fp32 tensors (newer torchrl): what oracle_per_sample evaluates --
+ *                  ATen special-cases the exponent -0.5 to 1 / sqrt(x), two correctly rounded fp32 operations;
+ *   weight_form 1  np.power(p / p_min, -beta) on fp32 NumPy arrays (older torchrl): the C library's powf(x, -beta), one
+ *                  rounding (glibc's powf is correctly rounded in almost every case).
+ *   query_full != 0  p_sum / p_min taken over query(0, max_capacity) instead of query(0, len): the same nodes once the
+ *                  storage is full (len == size -- the benched state); while it fills, the whole-range shortcut returns the
+ *                  root, whose fp32 sum may round differently from the bottom-up walk over [0, len).
+ * The sampled INDICES depend on neither the weight form nor -- once the storage is full -- the query range.
+ */
+void oracle_per_sample_variant(const seg_tree *sum_t, const seg_tree *min_t, int64_t len, const float *mass,
+                               int64_t n, float beta, int weight_form, int query_full, int64_t *out_index,
+                               float *out_weight, float *out_psum_pmin) {
+    float p_sum = oracle_tree_query(sum_t, 0, query_full ? sum_t->size : len);
+    float p_min = oracle_tree_query(min_t, 0, query_full ? min_t->size : len);
+    if (out_psum_pmin) {
+        out_psum_pmin[0] = p_sum;
+        out_psum_pmin[1] = p_min;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t idx = oracle_tree_scan_lower_bound(sum_t, mass[i]);
+        if (idx > len - 1) idx = len - 1;
+        out_index[i] = idx;
+        float w = oracle_tree_get(sum_t, idx) / p_min;
+        out_weight[i] = weight_form == 1 ? powf(w, -beta) : pow_neg_beta(w, beta);
+    }
+}
+
+/*
  * PrioritizedSampler.update_priority: running max over the raw priorities, then
  * p = (priority + eps) ** alpha written to both trees, sequentially (last duplicate wins).
  * Returns the new running max.

@@ -49,6 +49,7 @@ def lib():
         L.oracle_tree_scan_lower_bound.restype = i64
         L.oracle_tree_scan_lower_bound.argtypes = [vp, f32]
         L.oracle_per_sample.argtypes = [vp, vp, i64, vp, i64, f32, vp, vp, vp]
+        L.oracle_per_sample_variant.argtypes = [vp, vp, i64, vp, i64, f32, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         L.oracle_default_priority.restype = f32
         L.oracle_default_priority.argtypes = [f32, f32, f32]
         L.oracle_per_update.restype = f32
@@ -127,6 +128,15 @@ class PrioritizedSamplerOracle:
                                 self.beta, _p(idx), _p(w), _p(ps))
         if not (ps[0] > 0) or not (ps[1] > 0):
             raise RuntimeError("non-positive p_sum / p_min")
+        return idx, w, float(ps[0]), float(ps[1])
+
+    def sample_variant(self, length, mass, weight_form=0, query_full=False):
+        """``sample`` under the torchrl version variants per_oracle.c documents (np.power weights, whole-capacity query)."""
+        mass = np.ascontiguousarray(mass, dtype=np.float32)
+        n = mass.size
+        idx, w, ps = np.empty(n, np.int64), np.empty(n, np.float32), np.empty(2, np.float32)
+        lib().oracle_per_sample_variant(self.sum_tree._h, self.min_tree._h, int(length), _p(mass), n, self.beta,
+                                        int(weight_form), int(bool(query_full)), _p(idx), _p(w), _p(ps))
         return idx, w, float(ps[0]), float(ps[1])
 
     def update_priority(self, index, priority):

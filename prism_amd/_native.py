@@ -15,7 +15,7 @@ PRISM_OK, PRISM_ERR_INVALID, PRISM_ERR_HIP, PRISM_ERR_UNSUPPORTED = 0, -1, -2, -
 PRISM_MAX_NSTEP = 15
 FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 STATUS_NONPOSITIVE_PSUM, STATUS_NONPOSITIVE_PMIN = 1, 2
-WS_STATUS_WORD, WS_STATUS_BARRIER_TIMEOUT = 7, 1
+WS_STATUS_WORD, WS_STATUS_BARRIER_TIMEOUT, WS_STATUS_COLLECTIVE_TIMEOUT = 7, 1, 2
 GEMM_MODES = {"auto": 0, "fp32": 1, "bf16x3": 2}
 
 c_i32, c_i64, c_u64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
@@ -67,14 +67,16 @@ class LearnerDesc(ctypes.Structure):
                 ("fuse_tail", c_i32), ("gemm_mode", c_i32),
                 ("out_dist_loss", c_vp), ("out_q_loss", c_vp), ("out_td", c_vp), ("out_scalars", c_vp),
                 ("dbg_z", c_vp), ("dbg_stamps", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
-                ("hyper", AdamHyper)]
+                ("hyper", AdamHyper), ("host_status", c_vp)]
 
 
 MAX_PEERS = 8
+DIRECT_FLAG_WORDS, IPC_HANDLE_BYTES = MAX_PEERS + 2, 64
 
 
 class DirectDesc(ctypes.Structure):
-    _fields_ = [("world", c_i32), ("rank", c_i32), ("bufs", c_vp * MAX_PEERS), ("flags", c_vp * MAX_PEERS), ("n", c_i64)]
+    _fields_ = [("world", c_i32), ("rank", c_i32), ("bufs", c_vp * MAX_PEERS), ("flags", c_vp * MAX_PEERS), ("n", c_i64),
+                ("poison", c_vp), ("host_status", c_vp), ("wait_seconds", ctypes.c_double)]
 
 
 _P = ctypes.POINTER
@@ -108,6 +110,13 @@ SIGNATURES = {
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "prism_direct_reduce_scatter": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),
     "prism_direct_all_gather": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),
+    "prism_direct_phase": (ctypes.c_int, [_P(DirectDesc), c_i32, c_i32, c_vp]),
+    "prism_direct_flags_alloc": (ctypes.c_int, [_P(c_vp), c_vp]),
+    "prism_direct_flags_free": (ctypes.c_int, [c_vp]),
+    "prism_direct_flags_open": (ctypes.c_int, [c_vp, _P(c_vp)]),
+    "prism_direct_flags_close": (ctypes.c_int, [c_vp]),
+    "prism_direct_enable_peer": (ctypes.c_int, [c_i32]),
+    "prism_direct_flags_read": (ctypes.c_int, [c_vp, c_vp, c_vp]),
     "prism_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "prism_profile_collect": (ctypes.c_int, [_P(ctypes.c_double), _P(c_i64)]),
     "prism_profile_kernel_name": (ctypes.c_char_p, [ctypes.c_int]),
@@ -135,7 +144,7 @@ def lib():
             except AttributeError as e:
                 raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype, fn.argtypes = res, args
-        if L.prism_abi_version() != 2:
+        if L.prism_abi_version() != 3:
             raise NativeLibraryError("ABI version mismatch between prism_amd and libprism_hip.so")
         _lib = L
     return _lib

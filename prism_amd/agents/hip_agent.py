@@ -200,14 +200,17 @@ class HipAgent:
         # until a multi-GPU run of it is on record; the default is two graphs around an eagerly launched collective
         self.collective_in_graph = bool(getattr(config, "collective_in_graph",
                                                 os.environ.get("PRISM_COLLECTIVE_IN_GRAPH", "0") == "1"))
-        self.fuse_tail = bool(getattr(config, "fuse_tail", True))
+        # the fused tail's grid barrier needs the launch resident at once, which the library can only prove for a GPU this
+        # process has to itself: PRISM_SHARED_GPU=1 (several learners per GPU, a normal MinAtar set-up) switches it off
+        self.fuse_tail = bool(getattr(config, "fuse_tail", os.environ.get("PRISM_SHARED_GPU", "0") != "1"))
+        self._status = pdist.StatusWords()        # pinned host mirror of the sticky status bits: polled every step
         self._capture_error = None
         # the step's one exchange: "rccl" (torch.distributed all_reduce, the default) or "direct" (two shots over peer-mapped
         # buffers, prism_amd/dist.py DirectAllReduce)
         self.collective = str(getattr(config, "collective", "rccl"))
         self._direct = None
         if self.world > 1 and self.collective == "direct":
-            self._direct = pdist.DirectAllReduce(self.grads, self.pg)
+            self._direct = pdist.DirectAllReduce(self.grads, self.pg, status=self._status)
             if not self._direct.use_flags:
                 self.collective_in_graph = False          # host-side barriers cannot be captured
         self.model.train()
@@ -248,6 +251,9 @@ class HipAgent:
         d.out_dist_loss, d.out_q_loss = self.out_dl.data_ptr(), self.out_ql.data_ptr()
         d.out_td, d.out_scalars = self.out_td.data_ptr(), self.scalars.data_ptr()
         d.workspace, d.workspace_bytes = self.workspace.data_ptr(), ws_bytes
+        d.host_status = self._status.data_ptr()
+        if self._direct is not None:      # a collective that gives up poisons THIS workspace's status word (no update applied)
+            self._direct._desc.poison = self.workspace.data_ptr() + 4 * N.WS_STATUS_WORD
         self.rng_counters = torch.zeros(2, dtype=torch.int64, device=dev)     # {PER draws, tau draws}
         self._desc, self._B = d, B
         self._graphs = {}
@@ -373,6 +379,7 @@ class HipAgent:
             raise RuntimeError("fused step draws its random numbers in-kernel (per_mass_rng/tau_rng = 'philox')")
         if buf._index is None or buf._index.shape[0] != buf.buffer._batch_size:
             buf._alloc_batch(buf.buffer._batch_size)
+        self.poll_status()
         d = self._bind_fused(buf)
         d.rng_counters = self.rng_counters.data_ptr()
         d.offset = self._draw_offset               # device counter + what update() has consumed: never the same draw twice
@@ -515,6 +522,15 @@ class HipAgent:
         n, A = int(obs.shape[0]), self.dims.n_actions
         if type(sel) is EGreedyActionSelector:
             if sel.rng.uniform(0, 1) < sel.epsilon.update(n):       # one coin for the whole call (action_selectors.py:38-41)
+                # the reference has ALREADY run the model by the time it tosses the coin (agent.py:33 -> :36): the forward's
+                # quantile samples are drawn whether or not the estimates are used.  The estimates are not needed here, the
+                # draws are: consume them, so that every later greedy action sees the stream it would see in the reference
+                if self.dims.use_iqn:
+                    T = int(self.model.distribution_model.n_quantile_samples_per_action)
+                    if self.tau_rng == "torch":
+                        torch.rand([T * n, 1], device=self.device)
+                    else:
+                        self._act_draws += T * n
                 return torch.as_tensor(sel.rng.randint(A, size=(n,)), dtype=torch.long).to(self.device)
             sel = sel.greedy
         if self._B is None:
@@ -547,19 +563,39 @@ class HipAgent:
             return action
         return sel.select_action(sel.generate_action_probs(dist, q))
 
-    def check_status(self):
-        """Raise if a fused-tail grid barrier was abandoned (sticky status word of the workspace; one D2H sync).  That only
-        happens when the launch was not resident at once after all -- other processes' kernels on the same GPU -- and
-        leaves the step that hit it half applied; the agent switches the fused tail off for what follows."""
-        if self._B is None:
-            return
-        bits = int(self.workspace.view(torch.int32)[N.WS_STATUS_WORD].item())
-        if bits & N.WS_STATUS_BARRIER_TIMEOUT:
-            self.fuse_tail = False
-            self._graphs = {}
+    def _raise_status(self, bits):
+        self._status.clear()
+        if self._B is not None:
             self.workspace.view(torch.int32)[N.WS_STATUS_WORD] = 0
-            raise RuntimeError("prism_amd: a fused-tail grid barrier timed out (is the GPU shared with another process?); "
-                               "the last steps are incomplete -- restore a checkpoint; fuse_tail is now off")
+        self._graphs = {}
+        if bits & N.WS_STATUS_COLLECTIVE_TIMEOUT:
+            raise pdist.CollectiveTimeout("prism_amd: the direct all-reduce gave up on a peer; the step that hit it applied no "
+                                          "update and the replicas may have diverged -- restore a checkpoint")
+        self.fuse_tail = False
+        raise RuntimeError("prism_amd: a fused-tail grid barrier timed out (is the GPU shared with another process?); "
+                           "the last steps are incomplete -- restore a checkpoint; fuse_tail is now off")
+
+    def poll_status(self):
+        """Raise if a kernel has raised a sticky status bit since the last look: an abandoned fused-tail grid barrier or a
+        collective that gave up on a peer.  Reads the pinned host mirror of the bits (``prism_learner_desc.host_status``):
+        no device synchronisation, so every ``step_fused`` / ``Learner.step`` calls it -- a failed step surfaces one step
+        late at most, not at the next ``log()``."""
+        bits = self._status.bits()
+        if bits:
+            self._raise_status(bits)
+
+    def check_status(self):
+        """``poll_status`` plus the device's own words (one D2H sync): the workspace status word and, data parallel with the
+        direct collective, the sticky slot of the flag array.  An abandoned grid barrier only happens when the launch was not
+        resident at once after all -- other processes' kernels on the same GPU -- and leaves the step that hit it half
+        applied; the agent switches the fused tail off for what follows."""
+        self.poll_status()
+        if self._B is not None:
+            bits = int(self.workspace.view(torch.int32)[N.WS_STATUS_WORD].item())
+            if bits & (N.WS_STATUS_BARRIER_TIMEOUT | N.WS_STATUS_COLLECTIVE_TIMEOUT):
+                self._raise_status(bits)
+        if self._direct is not None:
+            self._direct.check_status()
 
     def _target_changed(self):
         """The target parameters were written: its stream-packed copies in the workspace are stale (word 2 of the

@@ -462,6 +462,8 @@ static void fill_adam_args(const prism_learner_desc *ld, const IqnWs &ws, AdamAr
     a.grad_scale = ld->hyper.grad_scale;
     a.out_scalars = ld->out_scalars;
     a.ticket = ws.ticket;
+    // data parallel (the gradient is scaled by 1 / world): a collective that gave up on a peer poisons the step
+    a.poison = ld->hyper.grad_scale != 1.0f ? ws.ticket + PRISM_WS_STATUS_WORD : nullptr;
 }
 
 static int adam_blocks(int64_t n) {
@@ -987,7 +989,8 @@ extern "C" int prism_step_back(const prism_learner_desc *ld, const prism_replay_
         TailArgs t;
         t.adam = a;
         t.barrier = reinterpret_cast<unsigned long long *>(ws.ticket + 4);
-        t.status = ws.ticket + 7;
+        t.status = ws.ticket + PRISM_WS_STATUS_WORD;
+        t.host_status = ld->host_status;
         t.rng = k.rng;
         t.inc_per = k.inc_per;
         t.inc_tau = k.inc_tau;

@@ -477,6 +477,7 @@ struct AdamArgs {
     float max_norm, grad_scale;
     float *out_scalars;
     unsigned int *ticket;
+    const unsigned int *poison;    // data parallel: the workspace status word (PRISM_WS_STATUS_COLLECTIVE_TIMEOUT), else NULL
 };
 
 // One NT-thread block of the clip + Adam update (block `blk` of `nblk`).  The operands of the block's first
@@ -488,6 +489,9 @@ __device__ __forceinline__ void clip_adam_block(const AdamArgs &a, int blk, int 
     __shared__ float s_red[256];
     __shared__ float s_c[4];     // clip coef, -step_size, sqrt(bias_correction2)
     const int tid = threadIdx.x;
+    // the all-reduce in front of this launch gave up on a peer (direct.hip): the gradient is not a sum over all ranks --
+    // apply NOTHING (uniform over the grid: every block reads the same sticky word; the host raises at its next poll)
+    if (a.poison && (__hip_atomic_load(a.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & PRISM_WS_STATUS_COLLECTIVE_TIMEOUT)) return;
     const int64_t nvec = a.n >> 2;
     const int64_t i0 = (int64_t)blk * NT + tid;
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), p0 = g0, m0 = g0, v0 = g0;
@@ -614,7 +618,7 @@ __device__ __forceinline__ unsigned long long grid_barrier_arrive(unsigned long 
 }
 // returns false (in every thread) when the wait was abandoned
 __device__ __forceinline__ bool grid_barrier_wait(unsigned long long *bar, unsigned long long old, unsigned int n,
-                                                  unsigned int *status) {
+                                                  unsigned int *status, unsigned int *host_status = nullptr) {
     __shared__ int s_ok;
     if (threadIdx.x == 0) {
         const unsigned long long target = ((old >> 20) + 1ull) << 20;
@@ -632,6 +636,8 @@ __device__ __forceinline__ bool grid_barrier_wait(unsigned long long *bar, unsig
                     else if (now - t0 > GRID_WAIT_TICKS) {
                         ok = 0;
                         atomicOr(status, GRID_STATUS_TIMEOUT);
+                        // (word 0 of the host's pinned status words = bit 0: polled every step without a device sync)
+                        if (host_status) __hip_atomic_store(host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                 }
@@ -648,6 +654,7 @@ struct TailArgs {
     AdamArgs adam;
     unsigned long long *barrier;   // [1] arrivals, cumulative over all launches
     unsigned int *status;          // [1] sticky GRID_STATUS_* bits
+    unsigned int *host_status;     // optional pinned host words [4] mirroring the sticky bits (prism_learner_desc.host_status)
     uint64_t *rng;             // device RNG counters {PER draws, tau draws} advanced once per step (or NULL)
     uint64_t inc_per, inc_tau;
 };
@@ -672,7 +679,8 @@ struct TailShare {
 // the gradient where it is not owned), the 256-lane fold every launch shape uses, the update.  Bit-identical to
 // clip_adam_block.
 __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long long *barrier, unsigned int *status, int n_role,
-                                               const TailShare &sh, int64_t step_now, unsigned long long *st) {
+                                               const TailShare &sh, int64_t step_now, unsigned long long *st,
+                                               unsigned int *host_status = nullptr) {
     auto stamp = [&](int k) {
         if (st && threadIdx.x == 0) {
             st[(size_t)blockIdx.x * 64 + k] = __builtin_amdgcn_s_memtime();
@@ -699,7 +707,7 @@ __device__ __forceinline__ void tail_clip_adam(const AdamArgs &a, unsigned long 
         s_c[1] = (float)(-(a.lr / bc1));
         s_c[2] = (float)sqrt(bc2);
     }
-    if (!grid_barrier_wait(barrier, ticket, (unsigned)n_role, status)) return;      // (uniform: abandoned, flagged)
+    if (!grid_barrier_wait(barrier, ticket, (unsigned)n_role, status, host_status)) return;      // (uniform: abandoned, flagged)
     stamp(25);
     // (everything another workgroup wrote is read at agent scope: the barrier has no acquire)
     auto far = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -1083,7 +1091,8 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             sh.j = sh.k < sh.s0 ? sh.k : sh.k + sh.cnt;
             sh.scalar_tail = rank == 0;
         }
-        tail_clip_adam(tl.adam, tl.barrier, tl.status, n_role, sh, step_now, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr);
+        tail_clip_adam(tl.adam, tl.barrier, tl.status, n_role, sh, step_now, (a.dbg & 8) ? (unsigned long long *)a.stamps : nullptr,
+                       tl.host_status);
         if (!wb.enabled && tl.rng && blockIdx.x == 0 && tid == 0) {
             tl.rng[0] += tl.inc_per;
             tl.rng[1] += tl.inc_tau;

@@ -124,3 +124,10 @@ def philox_per_mass(seed, offset, batch, p_sum):
     a, b = (r[:, 0] >> np.uint32(5)).astype(np.float64), (r[:, 1] >> np.uint32(6)).astype(np.float64)
     u = (a * 67108864.0 + b) / 9007199254740992.0
     return (0.0 + (np.float64(np.float32(p_sum)) - 0.0) * u).astype(np.float32)
+
+
+def philox_uniform_index(seed, offset, batch, size):
+    """The slots uniform_sample_kernel / step_front_kernel draw for uniform replay (torchrl RandomSampler,
+    exp_buffer_factory.py:30-33): floor(x * size / 2**64) of a 64-bit Philox word, key "UNIF"."""
+    r = philox4x32(seed, np.uint64(offset) + np.arange(batch, dtype=np.uint64), 0x554E4946)
+    return np.array([((int(a) << 32 | int(b)) * int(size)) >> 64 for a, b in zip(r[:, 0], r[:, 1])], dtype=np.int64)

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(raw, n), f"{n} declared in prism_hip.h but not exported"
         assert n in N.SIGNATURES, f"{n} has no ctypes signature in prism_amd/_native.py"
     assert set(N.SIGNATURES) == set(names)
-    assert lib.prism_abi_version() == 2
+    assert lib.prism_abi_version() == 3
     # (documentation drift guard: DESIGN.md quotes the number of entry points)
     assert f"({len(names)} entry points)" in open(os.path.join(H.ROOT, "DESIGN.md")).read()
 
@@ -45,8 +45,9 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.ModelDims) == 16 * 4 + 4 * 4
     assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
     assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4
-    # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40)
-    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 7 * 8 + 8 + 40
+    # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40), host_status
+    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 7 * 8 + 8 + 40 + 8
+    assert ctypes.sizeof(N.DirectDesc) == 8 + 8 * 8 + 8 * 8 + 8 + 8 + 8 + 8
 
 
 def test_argument_checks_without_device(lib):

@@ -193,7 +193,14 @@ def test_forward_selects_natively_also_in_pieces(dev, name):
     agent.action_selector = EGreedyActionSelector(1.0, 1.0, 0, seed=7)
     twin = np.random.RandomState(7)
     twin.uniform(0, 1)
+    draws0 = agent._act_draws
     np.testing.assert_array_equal(agent.forward(obs).cpu().numpy(), twin.randint(A, size=(n,)))
+    # the explore branch consumes the forward's quantile draws like the reference, which runs the model BEFORE the coin
+    # (agent.py:33-36): the streams of explore-then-greedy sequences stay aligned
+    if agent.dims.use_iqn:
+        assert agent._act_draws == draws0 + n * int(agent.model.distribution_model.n_quantile_samples_per_action)
+    else:
+        assert agent._act_draws == draws0
     agent.action_selector = EGreedyActionSelector(0.0, 0.0, 0, seed=7)
     agent._act_draws = 5000
     act = agent.forward(obs)

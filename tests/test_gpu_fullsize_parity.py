@@ -71,8 +71,9 @@ def _check_step(ln, cfg, orc_ring, step):
     sd0 = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
     tg0 = None if agent.target_model is None else {k: v.detach().cpu().clone() for k, v in agent.target_model.state_dict().items()}
     opt0 = agent.optimizer.state_dict()
-    sum0, min0 = buf.sum_tree.cpu().numpy().copy(), buf.min_tree.cpu().numpy().copy()
-    max0 = float(buf.per_state[0].item())
+    if buf.use_per:
+        sum0, min0 = buf.sum_tree.cpu().numpy().copy(), buf.min_tree.cpu().numpy().copy()
+        max0 = float(buf.per_state[0].item())
     per_ctr = int(agent.rng_counters[0].item()) if agent._B is not None else 0
     draws0 = buf._draws
     td = ln.step(timesteps_this_iteration=1).clone()
@@ -83,16 +84,22 @@ def _check_step(ln, cfg, orc_ring, step):
 
     # ---- sampling: same trees, same masses -> same slots and IS weights
     smp = orc_ring.sampler
-    smp.sum_tree.values()[:] = sum0
-    smp.min_tree.values()[:] = min0
-    smp.max_priority = max0
-    p_sum = smp.sum_tree.query(0, buf._size)
-    mass = H.philox_per_mass(buf.seed, draws0 + per_ctr, B, p_sum)
-    idx_o, w_o, ps_o, pm_o = smp.sample(buf._size, mass)
     idx = buf._index.cpu().numpy()
-    np.testing.assert_array_equal(idx, idx_o, err_msg=f"step {step}: sampled slots")
-    np.testing.assert_array_equal(buf._weight.cpu().numpy(), w_o, err_msg=f"step {step}: IS weights")
-    assert np.float32(ps_o) == np.float32(buf.per_state[1].item()) and np.float32(pm_o) == np.float32(buf.per_state[2].item())
+    if buf.use_per:
+        smp.sum_tree.values()[:] = sum0
+        smp.min_tree.values()[:] = min0
+        smp.max_priority = max0
+        p_sum = smp.sum_tree.query(0, buf._size)
+        mass = H.philox_per_mass(buf.seed, draws0 + per_ctr, B, p_sum)
+        idx_o, w_o, ps_o, pm_o = smp.sample(buf._size, mass)
+        np.testing.assert_array_equal(idx, idx_o, err_msg=f"step {step}: sampled slots")
+        np.testing.assert_array_equal(buf._weight.cpu().numpy(), w_o, err_msg=f"step {step}: IS weights")
+        assert np.float32(ps_o) == np.float32(buf.per_state[1].item()) and np.float32(pm_o) == np.float32(buf.per_state[2].item())
+    else:
+        # uniform replay (configs[0]; exp_buffer_factory.py:30-33): slot = floor(u * size) of the same Philox word, IS weight 1
+        idx_o = H.philox_uniform_index(buf.seed, draws0 + per_ctr, B, buf._size)
+        np.testing.assert_array_equal(idx, idx_o, err_msg=f"step {step}: uniformly sampled slots")
+        w_o = np.ones(B, dtype=np.float32)
     # ---- n-step walk + collate
     _fill_rows(orc_ring, buf, idx)
     g = orc_ring.gather(idx)
@@ -149,6 +156,8 @@ def _check_step(ln, cfg, orc_ring, step):
             needed.append(k)
         perr = max(perr, d)
     assert len(needed) <= 4, f"step {step}: {needed} needed the ill-conditioning allowance"
+    if not buf.use_per:
+        return err, perr, B - len(np.unique(idx))
     # ---- priority writeback with the device's own |td|: every node of both trees, duplicates included
     smp.update_priority(idx, td_d.abs().numpy())
     np.testing.assert_array_equal(buf.sum_tree.cpu().numpy(), smp.sum_tree.values(), err_msg=f"step {step}: sum tree")
@@ -157,9 +166,10 @@ def _check_step(ln, cfg, orc_ring, step):
     return err, perr, B - len(np.unique(idx))
 
 
-# (configs[1], [2], [3] of BASELINE.json at full size; configs[3] again without the fused tail -- the launch form a
+# (configs[0], [1], [2], [3] of BASELINE.json at full size; configs[3] again without the fused tail -- the launch form a
 #  data-parallel step uses; the 1.25 M-slot shard of configs[4]: 21 tree levels)
 CASES = {
+    "c1_dqn_uniform": dict(base=0, B=32, cap=100_000),
     "c2_dqn_per": dict(base=1, B=256, cap=100_000),
     "c3_iqn_per": dict(base=2, B=256, cap=100_000),
     "c4_full": dict(base=3, B=512, cap=100_000, target_update_period=40),

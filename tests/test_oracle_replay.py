@@ -109,3 +109,41 @@ def test_sampler_semantics():
     assert w.max() <= 1.0 + 1e-6 and abs(p_min - s.sum_tree.get(3)) < 1e-7
     s.add(700)
     assert abs(s.sum_tree.get(700) - (9.0 + 1e-8) ** 0.5) < 1e-6
+
+
+def test_torchrl_version_variants_of_the_sampler():
+    """The reference pins no torchrl version.  Two things changed in torchrl's sampler over time (oracle/per_oracle.c,
+    oracle_per_sample_variant); this states what each changes, so the assumption is tested instead of silent:
+      * IS weights through ``np.power`` (older) instead of ``torch.pow`` (newer, what the oracle and the device evaluate):
+        indices identical, weights within one unit in the last place;
+      * p_sum / p_min over ``query(0, max_capacity)`` instead of ``query(0, len)``: identical in every output once the
+        storage is full (the benched state); while it fills only the fp32 rounding of p_sum may differ -- never an index
+        for the same masses."""
+    rng = np.random.default_rng(11)
+    cap = 5000
+    for alpha, beta in ((0.5, 0.5), (0.6, 0.4), (1.0, 1.0)):
+        smp = per_ref.PrioritizedSamplerOracle(cap, alpha, beta)
+        for length in (cap, 3123):
+            smp.sum_tree.values()[:] = 0.0
+            smp.min_tree.values()[:] = np.finfo(np.float32).max
+            idx = np.arange(length)
+            smp.update_priority(idx, np.abs(rng.standard_normal(length)).astype(np.float32) * 3.0)
+            mass = smp.draw_mass(length, 4096, rng)
+            i0, w0, ps0, pm0 = smp.sample(length, mass)
+            i00, w00, _, _ = smp.sample_variant(length, mass, 0, False)
+            np.testing.assert_array_equal(i0, i00)
+            np.testing.assert_array_equal(w0, w00)
+            i1, w1, ps1, pm1 = smp.sample_variant(length, mass, 1, False)           # np.power weights
+            np.testing.assert_array_equal(i0, i1)
+            ulp = np.spacing(np.maximum(np.abs(w0), np.abs(w1)).astype(np.float32))
+            assert np.all(np.abs(w0.astype(np.float64) - w1) <= ulp), "np.power and torch.pow weights differ by more than 1 ulp"
+            if alpha == 1.0 and beta == 1.0:
+                np.testing.assert_array_equal(w0, 1.0 / (smp.sum_tree.values()[i0 + smp.sum_tree.capacity] / np.float32(pm0)))
+            i2, w2, ps2, pm2 = smp.sample_variant(length, mass, 0, True)            # whole-capacity query
+            np.testing.assert_array_equal(i0, i2)
+            assert pm2 == pm0                                                       # min is order-free
+            if length == cap:
+                assert ps2 == ps0
+                np.testing.assert_array_equal(w0, w2)
+            else:
+                assert abs(ps2 - ps0) <= 4 * np.spacing(np.float32(ps0))
