@@ -52,6 +52,9 @@ constexpr int FW_ZS = 17;                        // row stride of the Z tile in 
 #ifndef FW_SPLIT_RING
 #define FW_SPLIT_RING 4                          // trunk operand groups a wave keeps in flight (3 KB each)
 #endif
+#ifndef FW_KO
+#define FW_KO 0                                  // knock-out experiments (tools/fwd_knockouts.sh): 1 no phi save, 2 no operand split, 4 half the weight bytes
+#endif
 constexpr int FW_CBS = 36;                       // row stride (dwords) of a bf16 cos plane: 32 dwords of pairs + 4 (rows li, li + 8 share banks: 2-way)
 
 // LDS of a forward tile (floats): cos tile | tau + loss scalars | row-stat partials | K-slice partials | Z tile | head
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         const gcu4 wp = reinterpret_cast<gcu4>(ps_wpk) + (kind == 1 ? (size_t)hd * (32 * NHT * 3 * 64) : (size_t)0) +
                         (size_t)(4 * w) * G * 3 * 64 + lane;
         auto slot = [&](int ds, int group, int plane) __attribute__((always_inline)) { return wp[((ds * G + group) * 3 + plane) * 64]; };
+        constexpr bool KO_HALF = (FW_KO & 4) != 0;      // (wrong numbers: the second half of the stream re-uses stale operand registers)
         const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
         const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
         // prepared quantile samples + basis pieces of this tile (cos_basis_block): the first requests of the stream
@@ -514,11 +518,15 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         float *const phi_dst = (PHI && myrow.save >= 0)
                                    ? a.ws.phis + ((myrow.save >> 4) * (int64_t)(E_DIM / 16) + 8 * w) * 256 + (myrow.save & 15) * 16 + 4 * g
                                    : nullptr;
+        // (ReLU(phi) for the backward launch goes out from inside the stream, 16 bytes per lane and n-tile.  Knock-out, same
+        // box: without these stores the tile takes 20.9 instead of 22.4 us -- but parking the values in LDS and storing them
+        // behind the last MFMA group only moved the cost: forward -0.3 us, backward +0.2 us (r04): what costs is the 8 MB
+        // that have to be out before the launch ends, not the stores' place in the wave's memory queue.)
         // phi group p (0 .. 4 NDS - 1): double step p >> 2, n-tile (p >> 1) & 1, K block p & 1; ring slot p & 1
         auto phi_group = [&](int p) __attribute__((always_inline)) {
             const int nt2 = (p >> 1) & 1, kb = p & 1;
             pacc[nt2] = mfma_split(wph[p & 1][0], wph[p & 1][1], wph[p & 1][2], cos_operand(kb), pacc[nt2]);
-            if (p + 2 < NP) {
+            if (p + 2 < (KO_HALF ? NP / 2 : NP)) {
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) wph[p & 1][pl] = slot((p + 2) >> 2, (p + 2) & 3, pl);
             }
@@ -543,14 +551,18 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                     }
                     xv[4 * t + r] = v;
                 }
-                if (PHI && phi_dst) __builtin_nontemporal_store(ph4, reinterpret_cast<f32x4 *>(phi_dst + 256 * (2 * ds + t)));
+                if (PHI && phi_dst && !(FW_KO & 1)) __builtin_nontemporal_store(ph4, reinterpret_cast<f32x4 *>(phi_dst + 256 * (2 * ds + t)));
                 if (ds + 1 < NDS) {
                     e4[t] = *reinterpret_cast<gcf4>(erow + 32 * (ds + 1) + 16 * t);
                     if (PHI) b4[t] = *reinterpret_cast<gcf4>(brow + 32 * (ds + 1) + 16 * t);
                 }
                 if (PHI) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            xs = split_bf16x3(xv);
+            if constexpr ((FW_KO & 2) != 0) {
+                if (ds == 0) xs = split_bf16x3(xv);
+                else asm volatile("" ::"v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]), "v"(xv[4]), "v"(xv[5]), "v"(xv[6]), "v"(xv[7]));
+            } else
+                xs = split_bf16x3(xv);
         };
         if (PHI) {
 #pragma unroll
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             for (int ht = 0; ht < NHT; ++ht) {
                 const int q = ds * NHT + ht, sl = q % RW;
                 accT[ht] = mfma_split(w1r[sl][0], w1r[sl][1], w1r[sl][2], xs, accT[ht]);
-                if (q + RW < NQ) {
+                if (q + RW < (KO_HALF ? NQ / 2 : NQ)) {
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) w1r[sl][pl] = slot((q + RW) / NHT, P0 + (q + RW) % NHT, pl);
                 }
