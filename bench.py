@@ -450,6 +450,22 @@ def main():
                "roofline": roof}
         if dp_info:
             out["data_parallel"] = dp_info
+        if world == 1:
+            # the loop's other half: one Agent.forward per update in the MinAtar presets -- host array in,
+            # actions on the host out, replayed from its hipGraph; median over 300 calls each
+            act = {}
+            rng_a = np.random.default_rng(7)
+            for n_obs in (1, 16):
+                o = (rng_a.random((n_obs, 10, 10, 4)) < 0.1).astype(np.float32)
+                for _ in range(20):
+                    agent.forward(o).cpu()
+                ts = []
+                for _ in range(300):
+                    t0 = time.perf_counter()
+                    agent.forward(o).cpu()
+                    ts.append(time.perf_counter() - t0)
+                act[f"n_obs_{n_obs}"] = round(float(np.median(ts)) * 1e6, 1)
+            out["acting_latency_us"] = dict(act, what="Agent.forward host -> host (agent.py:31-41), hipGraph replay, median of 300")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

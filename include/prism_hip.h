@@ -38,6 +38,8 @@ extern "C" {
 #define PRISM_GEMM_BF16X3 2
 #define PRISM_GEMM_DEFAULT PRISM_GEMM_BF16X3
 
+#define PRISM_ACT_WEIGHTS_CURRENT 1
+
 /* per-slot flag bits of the replay ring */
 #define PRISM_FLAG_DONE 1u      /* Timestep.done                                            */
 #define PRISM_FLAG_TRUNC 2u     /* Timestep.truncated                                       */
@@ -212,9 +214,9 @@ typedef struct prism_learner_desc {
     const float *tau_next_target; /* [T'*B] used when has_target                              */
     float *tau_out;           /* [3][max(T,T')*B] or NULL                                     */
     uint64_t seed, offset;
-    uint64_t *rng_counters;   /* optional device [2] {PER draws, tau draws} added to the immediate offsets
-                                 and advanced by prism_step_back (lets a captured hipGraph draw fresh
-                                 numbers on every replay); NULL = immediate offsets only              */
+    uint64_t *rng_counters;   /* optional device [3] {PER draws, tau draws, acting draws} added to the immediate
+                                 offsets; [0], [1] are advanced by prism_step_back, [2] by prism_act_forward (lets a
+                                 captured hipGraph draw fresh numbers on every replay); NULL = immediate offsets only */
     /* Optional: when fused_replay is set, prism_per_update(fused_index, |out_td|) rides along in the
      * learner's launches instead of being a workgroup of its own in prism_step_back: one more workgroup
      * of prism_learner_fwd_bwd's last launch prepares it (|TD|^alpha, ranking, duplicate resolution --
@@ -236,6 +238,10 @@ typedef struct prism_learner_desc {
      * is not through after 100 ms is abandoned: the workgroup sets PRISM_WS_STATUS_BARRIER_TIMEOUT in the workspace's
      * status word and skips its update instead of spinning for ever. */
     int32_t fuse_tail;
+    /* prism_act_forward only.  PRISM_ACT_WEIGHTS_CURRENT: the stream-packed weight copies and LayerNorm helper vectors in
+     * the workspace were built from `params` as they are now (an earlier prism_act_forward without this flag ran since the
+     * parameters last changed): the call skips rebuilding them.  0 is always correct. */
+    int32_t act_flags;
     /* How the forward GEMMs (quantile embedding, trunk, Q-head first layers) are multiplied: PRISM_GEMM_FP32 = the exact
      * fp32 MFMA chain; PRISM_GEMM_BF16X3 = every fp32 operand as the sum of three bf16 pieces, the six leading piece
      * products on the bf16 matrix pipe with fp32 accumulation (what is dropped is of the size of one fp32 rounding; same rms
@@ -305,13 +311,16 @@ int prism_step_back(const prism_learner_desc *ld, const prism_replay_desc *rp, c
  * Acting forward -- Agent.forward (prism/agents/agent.py:31-41): CompositeModel.forward(for_action=True)
  * (composite_model.py:51-70; iqn_model.py:61-87 with n_quantile_samples_per_action rows per observation;
  * q_ensemble.py:44-48) on the learner's parameters and workspace, with the same forward tiles as the update.
- *   obs      [n][10][10][C], 1 <= n <= ld->batch (Q heads: the 16-padded n as well)
+ *   obs      [n][10][10][C], 1 <= n <= ld->batch (Q heads: the 16-padded n as well); device memory, or pinned
+ *            device-mapped host memory read in place (no host-to-device copy in front of a small batch)
  *   tau_in   [n_tau*n] tau-major (row = t*n + b, iqn_model.py:66-70) or NULL -> Philox(seed, offset)
  *   out_z    [ceil16(n*n_tau)][A]  quantile estimates, SAMPLE-major (row = b*n_tau + t); reference layout =
  *            view(n, n_tau, A).permute(1, 0, 2)
  *   out_q    [heads][ceil16(n)][A] ensemble estimates; reference layout = [:, :n].permute(1, 2, 0)
  *            (the single-Linear DQN head, dqn_n_model_layers = 1: heads = 1, one workgroup per observation)
- * Either output may be NULL when the model has no such part. */
+ * Either output may be NULL when the model has no such part.
+ * Quantile draws: Philox(seed, offset [+ ld->rng_counters[2] when ld->rng_counters is set and tau_in is NULL; the call then
+ * advances that device word by n * n_tau: capture the call into a hipGraph and every replay draws fresh samples]). */
 int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n, int32_t n_tau,
                       const float *tau_in, uint64_t seed, uint64_t offset, float *out_z, float *out_q,
                       prism_stream_t stream);
@@ -319,17 +328,19 @@ int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n,
 /* IDSActionSelector.generate_action_probs + select_action for ids_use_random_samples = False
  * (prism/agents/action_selectors.py:125-176): scores [n][A] = regret^2 / information gain, action [n] = argmin.
  * z / q: the buffers prism_act_forward filled.  out_aux (optional) [n][4][A]: ensemble mean, ensemble spread
- * (torch.std), return-distribution variance, information gain -- what the selector logs. */
+ * (torch.std), return-distribution variance, information gain -- what the selector logs.  out_action_host (optional): a
+ * second destination of the actions -- pinned, device-mapped host memory, so that the caller needs no device-to-host copy. */
 int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
                      int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
-                     float *out_aux, int64_t *out_action, prism_stream_t stream);
+                     float *out_aux, int64_t *out_action, int64_t *out_action_host, prism_stream_t stream);
 
 /* GreedyActionSelector.generate_action_probs + select_action (prism/agents/action_selectors.py:70-83; also the greedy
  * branch of EGreedyActionSelector, :24-45): action [n] = argmax_a mean(q_estimates[:, a, :]).  q != NULL: mean over the
  * n_heads ensemble estimates prism_act_forward left in out_q; q == NULL: mean over the n_tau quantile estimates in z
- * (composite_model.py:66-68, models without Q heads).  out_mean (optional) [n][A]. */
+ * (composite_model.py:66-68, models without Q heads).  out_mean (optional) [n][A]; out_action_host as for prism_ids_select. */
 int prism_greedy_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
-                        int32_t n_heads, int64_t *out_action, float *out_mean, prism_stream_t stream);
+                        int32_t n_heads, int64_t *out_action, float *out_mean, int64_t *out_action_host,
+                        prism_stream_t stream);
 
 /* Agent.sync_target_model (agent.py:149-152): target := online (device-to-device copy). */
 int prism_sync_target(float *target_params, const float *params, int64_t n_params,

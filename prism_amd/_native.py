@@ -17,6 +17,7 @@ FLAG_DONE, FLAG_TRUNC, FLAG_HAS_NEXT = 1, 2, 4
 STATUS_NONPOSITIVE_PSUM, STATUS_NONPOSITIVE_PMIN = 1, 2
 WS_STATUS_WORD, WS_STATUS_BARRIER_TIMEOUT, WS_STATUS_COLLECTIVE_TIMEOUT = 7, 1, 2
 GEMM_MODES = {"auto": 0, "fp32": 1, "bf16x3": 2}
+ACT_WEIGHTS_CURRENT = 1
 
 c_i32, c_i64, c_u64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_void_p
 
@@ -64,7 +65,7 @@ class LearnerDesc(ctypes.Structure):
                 ("tau_cur", c_vp), ("tau_next_online", c_vp), ("tau_next_target", c_vp), ("tau_out", c_vp),
                 ("seed", c_u64), ("offset", c_u64), ("rng_counters", c_vp),
                 ("fused_replay", c_vp), ("fused_index", c_vp), ("fused_alpha", c_f32), ("fused_eps", c_f32),
-                ("fuse_tail", c_i32), ("gemm_mode", c_i32),
+                ("fuse_tail", c_i32), ("act_flags", c_i32), ("gemm_mode", c_i32),
                 ("out_dist_loss", c_vp), ("out_q_loss", c_vp), ("out_td", c_vp), ("out_scalars", c_vp),
                 ("dbg_z", c_vp), ("dbg_stamps", c_vp), ("workspace", c_vp), ("workspace_bytes", ctypes.c_size_t),
                 ("hyper", AdamHyper), ("host_status", c_vp)]
@@ -105,8 +106,8 @@ SIGNATURES = {
     "prism_step_back": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_vp, c_f32, c_f32, c_vp]),
     "prism_act_forward": (ctypes.c_int, [_P(LearnerDesc), c_vp, c_i32, c_i32, c_vp, c_u64, c_u64, c_vp, c_vp, c_vp]),
     "prism_ids_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp,
-                                        c_vp, c_vp]),
-    "prism_greedy_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+                                        c_vp, c_vp, c_vp]),
+    "prism_greedy_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),
     "prism_direct_reduce_scatter": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),
     "prism_direct_all_gather": (ctypes.c_int, [_P(DirectDesc), c_i32, c_vp]),

@@ -157,6 +157,35 @@ def model_dims(config, in_channels, n_actions):
     return d
 
 
+class _Actions(torch.Tensor):
+    """What ``HipAgent.forward`` returns when it ran from its hipGraph: a device tensor like the reference's
+    (agent.py:41), whose ``.cpu()`` -- what every collector / evaluator calls next (experience_collector.py:127) -- hands
+    out the copy the graph's own device-to-host node already made into pinned memory: one event wait instead of a second
+    copy and a device synchronisation."""
+
+    @staticmethod
+    def wrap(dev, host, event):
+        t = dev.as_subclass(_Actions)
+        t._host, t._event = host, event
+        return t
+
+    def cpu(self, *a, **k):
+        host = getattr(self, "_host", None)
+        if host is None:
+            return torch.Tensor.cpu(self.as_subclass(torch.Tensor), *a, **k)
+        self._event.synchronize()
+        return host.clone()
+
+    def numpy(self, *a, **k):
+        return self.cpu().numpy()
+
+    def tolist(self):
+        return self.cpu().tolist()
+
+    def item(self):
+        return self.cpu().item()
+
+
 class HipAgent:
     def __init__(self, model, action_selector, eval_action_selector, target_model, config, in_channels,
                  n_actions, process_group=None):
@@ -204,6 +233,12 @@ class HipAgent:
         # process has to itself: PRISM_SHARED_GPU=1 (several learners per GPU, a normal MinAtar set-up) switches it off
         self.fuse_tail = bool(getattr(config, "fuse_tail", os.environ.get("PRISM_SHARED_GPU", "0") != "1"))
         self._status = pdist.StatusWords()        # pinned host mirror of the sticky status bits: polled every step
+        # Agent.forward replayed from one hipGraph per (number of observations, selector): H2D of the observations, embed,
+        # forward tiles, selector kernel, D2H of the actions (config.act_graph = False: the eager launches)
+        self.act_graph = bool(getattr(config, "act_graph", True))
+        self._param_epoch, self._act_packed_at = 0, None
+        # (the reference's async evaluator loads weights straight into agent.model, async_agent_evaluator.py:29)
+        self.model.register_load_state_dict_post_hook(lambda module, incompatible: self._params_replaced())
         self._capture_error = None
         # the step's one exchange: "rccl" (torch.distributed all_reduce, the default) or "direct" (two shots over peer-mapped
         # buffers, prism_amd/dist.py DirectAllReduce)
@@ -254,7 +289,8 @@ class HipAgent:
         d.host_status = self._status.data_ptr()
         if self._direct is not None:      # a collective that gives up poisons THIS workspace's status word (no update applied)
             self._direct._desc.poison = self.workspace.data_ptr() + 4 * N.WS_STATUS_WORD
-        self.rng_counters = torch.zeros(2, dtype=torch.int64, device=dev)     # {PER draws, tau draws}
+        self.rng_counters = torch.zeros(3, dtype=torch.int64, device=dev)     # {PER draws, tau draws, acting draws}
+        self._act_graphs, self._act_ptrs, self._act_dev_draws, self._act_packed_at = {}, {}, 0, None
         self._desc, self._B = d, B
         self._graphs = {}
 
@@ -518,8 +554,8 @@ class HipAgent:
         from prism_amd.agents.action_selectors import EGreedyActionSelector, GreedyActionSelector, IDSActionSelector
         from prism_amd.agents.modules import _as_tensor
         sel = self.eval_action_selector if self._is_eval else self.action_selector
-        obs = _as_tensor(obs, self.device).contiguous()
-        n, A = int(obs.shape[0]), self.dims.n_actions
+        obs_in = obs
+        n, A = int(np.shape(obs)[0]), self.dims.n_actions
         if type(sel) is EGreedyActionSelector:
             if sel.rng.uniform(0, 1) < sel.epsilon.update(n):       # one coin for the whole call (action_selectors.py:38-41)
                 # the reference has ALREADY run the model by the time it tosses the coin (agent.py:33 -> :36): the forward's
@@ -536,9 +572,129 @@ class HipAgent:
         if self._B is None:
             self._prepare(int(self.config.batch_size))
         cap = (self._B // 16) * 16 if (self.dims.n_heads > 0 and self.dims.head_layers == 2) else self._B
+        if n <= cap and self.act_graph and self.tau_rng == "philox":
+            out = self._forward_graph(obs_in, n, sel)
+            if out is not None:
+                return out
+        obs = _as_tensor(obs, self.device).contiguous()
         if n > cap:          # in pieces: every piece is selected from its own estimate buffers
             return torch.cat([self._forward_piece(obs[i:i + cap], sel) for i in range(0, n, cap)])
         return self._forward_piece(obs, sel)
+
+    def _forward_graph(self, obs_in, n, sel):
+        """One ``Agent.forward`` as ONE hipGraph launch: [observations host -> device] -> prism_act_forward -> selector kernel
+        -> [actions device -> pinned host].  Keyed by everything a capture bakes: the number of observations, where they come
+        from (the caller's device tensor by address -- the reference's collector reuses one inference buffer,
+        experience_collector.py:77-78 -- or the pinned staging block for host arrays), the selector and its constants.  The
+        quantile draws come from the device counter ``rng_counters[2]`` (include/prism_hip.h), which mirrors ``_act_draws``.
+        Returns None for selectors that have no native kernel (the caller runs the eager path)."""
+        from prism_amd.agents.action_selectors import GreedyActionSelector, IDSActionSelector
+        dm = self.dims
+        A = dm.n_actions
+        shape = (n, 10, 10, dm.in_channels)
+        q_tiles = dm.n_heads > 0 and dm.head_layers == 2
+        q_rows = dm.n_heads > 0 and dm.head_layers == 1
+        if type(sel) is IDSActionSelector:
+            if sel.random_sample or sel.unsquish_function is not None or not (dm.use_iqn and (q_tiles or q_rows)):
+                return None
+            skey = ("ids", float(sel.lmbda), float(sel.epsilon), float(sel.ids_rho_lower_bound))
+        elif type(sel) is GreedyActionSelector:
+            skey = ("greedy",)
+        else:
+            return None
+        if torch.is_tensor(obs_in) and obs_in.is_cuda and not (obs_in.dtype == torch.float32 and obs_in.is_contiguous()
+                                                               and obs_in.numel() == n * 100 * dm.in_channels):
+            obs_in = obs_in.float().contiguous().view(shape)          # (a device tensor in another layout: one eager copy)
+        on_host = not (torch.is_tensor(obs_in) and obs_in.is_cuda)
+        mode = "host" if on_host else "ptr"
+        if mode == "ptr":
+            # a device tensor is read in place while its address repeats (the collector's one inference buffer); a caller
+            # that hands over a fresh tensor every time gets one device-to-device copy into a staging block instead of a
+            # capture per address
+            seen = self._act_ptrs.setdefault((n, skey), set())
+            seen.add(obs_in.data_ptr())
+            if len(seen) > 3:
+                mode = "dev"
+        # the packed weight copies in the workspace follow the parameters: rebuilt by the first acting call after every update
+        current = self._act_packed_at == self._param_version()
+        key = (n, skey, mode, obs_in.data_ptr() if mode == "ptr" else None, self.seed, self._B, current)
+        st = self._act_graphs.get(key)
+        if st is None:
+            if len(self._act_graphs) > 32:
+                self._act_graphs.clear()
+            T = int(self.model.distribution_model.n_quantile_samples_per_action) if dm.use_iqn else 0
+            n_pad = (n + 15) // 16 * 16
+            dev = self.device
+            st = dict(T=T, n_pad=n_pad, calls=0, g=None,
+                      pin_in=[torch.zeros(shape, dtype=torch.float32).pin_memory() for _ in range(4)] if on_host else None,
+                      obs=obs_in if mode == "ptr" else (None if on_host else torch.empty(shape, dtype=torch.float32, device=dev)),
+                      z=torch.empty(((n * T + 15) // 16 * 16, A), device=dev) if dm.use_iqn else None,
+                      qb=torch.empty((dm.n_heads, n_pad, A), device=dev) if (q_tiles or q_rows) else None,
+                      scores=torch.empty((n, A), device=dev) if skey[0] == "ids" else None,
+                      act=[torch.empty(n, dtype=torch.int64, device=dev) for _ in range(4)],
+                      pin_out=[torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(4)],
+                      ev=[torch.cuda.Event() for _ in range(4)])
+            if st["pin_in"] is not None:
+                st["pin_np"] = [t.numpy() for t in st["pin_in"]]
+            self._act_graphs[key] = st
+        if self._act_dev_draws != self._act_draws:          # eager calls / an explore branch moved the host count on
+            self.rng_counters[2] = self._act_draws
+            self._act_dev_draws = self._act_draws
+        k = st["calls"] & 3
+        if on_host:
+            if st["calls"] >= 4:
+                st["ev"][k].synchronize()          # the launch that last read this staging slot (four calls ago) is through
+            if torch.is_tensor(obs_in):
+                st["pin_in"][k].copy_(obs_in.reshape(shape))
+            else:
+                st["pin_np"][k][...] = np.asarray(obs_in, dtype=np.float32).reshape(shape)
+        elif mode == "dev":
+            st["obs"].copy_(obs_in.view(shape))
+
+        def launch(slot):
+            # (host arrays: the embed kernel reads the pinned staging block in place -- 400 C bytes per observation over the
+            # host link cost less than a copy node in front of it; the selector writes the actions to device AND pinned host)
+            L, d, T = N.lib(), self._desc, st["T"]
+            keep = d.rng_counters, d.act_flags
+            d.rng_counters = self.rng_counters.data_ptr()
+            d.act_flags = N.ACT_WEIGHTS_CURRENT if current else 0
+            try:
+                N.check(L.prism_act_forward(ctypes.byref(d), N.ptr(st["pin_in"][slot] if on_host else st["obs"]), n, T, None, self.seed, 0,
+                                            N.ptr(st["z"]), N.ptr(st["qb"]), N.current_stream_handle()), "prism_act_forward")
+            finally:
+                d.rng_counters, d.act_flags = keep
+            if skey[0] == "ids":
+                N.check(L.prism_ids_select(N.ptr(st["z"]), N.ptr(st["qb"]), n, st["n_pad"], T, A, dm.n_heads, skey[1], skey[2],
+                                           skey[3], N.ptr(st["scores"]), None, N.ptr(st["act"][slot]), N.ptr(st["pin_out"][slot]),
+                                           N.current_stream_handle()), "prism_ids_select")
+            else:
+                N.check(L.prism_greedy_select(N.ptr(st["z"]), N.ptr(st["qb"]), n, st["n_pad"], T, A, dm.n_heads,
+                                              N.ptr(st["act"][slot]), None, N.ptr(st["pin_out"][slot]),
+                                              N.current_stream_handle()), "prism_greedy_select")
+
+        with torch.cuda.device(self.device):
+            if st["g"] is None and st["calls"] == 0:
+                launch(k)                                   # first call of this shape: eager (also warms the library up)
+            else:
+                if st["g"] is None:
+                    # second call: capture one graph per output slot (a slot is a baked address); a capture only records,
+                    # this call's work is the replay below
+                    torch.cuda.current_stream().synchronize()
+                    st["g"] = []
+                    for slot in range(4):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            launch(slot)
+                        st["g"].append(g)
+                st["g"][k].replay()
+            st["ev"][k].record()
+        self._act_packed_at = self._param_version()
+        st["calls"] += 1
+        self._act_draws += st["T"] * n
+        self._act_dev_draws = self._act_draws
+        self._act_raw = (st["z"], st["qb"], n, st["n_pad"], st["T"])
+        self._act_scores = st["scores"]
+        return _Actions.wrap(st["act"][k], st["pin_out"][k], st["ev"][k])
 
     def _forward_piece(self, obs, sel):
         from prism_amd.agents.action_selectors import GreedyActionSelector, IDSActionSelector
@@ -553,15 +709,22 @@ class HipAgent:
             with torch.cuda.device(self.device):
                 N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, float(sel.lmbda),
                                                  float(sel.epsilon), float(sel.ids_rho_lower_bound), N.ptr(scores), None,
-                                                 N.ptr(action), N.current_stream_handle()), "prism_ids_select")
+                                                 N.ptr(action), None, N.current_stream_handle()), "prism_ids_select")
             self._act_scores = scores
             return action
         if type(sel) is GreedyActionSelector:
             with torch.cuda.device(self.device):
                 N.check(N.lib().prism_greedy_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, N.ptr(action),
-                                                    None, N.current_stream_handle()), "prism_greedy_select")
+                                                    None, None, N.current_stream_handle()), "prism_greedy_select")
             return action
         return sel.select_action(sel.generate_action_probs(dist, q))
+
+    def _params_replaced(self):
+        self._param_epoch += 1
+
+    def _param_version(self):
+        """Changes whenever the online parameters may have: every update, checkpoint load, deserialisation."""
+        return (self.n_updates, self._param_epoch)
 
     def _raise_status(self, bits):
         self._status.clear()
@@ -630,6 +793,7 @@ class HipAgent:
 
     def deserialize_model(self, values):
         self.flat.copy_(torch.as_tensor(values, dtype=torch.float32))
+        self._param_epoch += 1
 
     def save(self, directory):
         """File layout of agent.py:179-203 (reference checkpoints interchange)."""
@@ -659,6 +823,7 @@ class HipAgent:
         with open(os.path.join(path, "state.pkl"), "rb") as f:
             state = ref_pickle.load(f)         # reference-written files name prism.agents.action_selectors.*
         self._graphs = {}                      # captured graphs bake the hyper-parameters restored here
+        self._param_epoch += 1
         self._target_changed()
         self.action_selector = state["action_selector"]
         self.eval_action_selector = state["eval_action_selector"]

@@ -131,6 +131,8 @@ struct IqnArgs {
     const int64_t *action;
     uint64_t seed, offset;
     const uint64_t *rng;   // device counters {PER draws, tau draws} or NULL
+    uint64_t *act_rng;     // acting forward replayed from a hipGraph: the device counter of its quantile draws, advanced by
+    uint64_t act_inc;      // act_inc by the embed launch (the tiles then read counter - act_inc through `rng` / `offset`)
     float *tau_out;        // [3][maxT*B] or NULL
     int maxT;
     float *out_dl, *out_ql, *out_td, *out_scalars;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void iqn_embed_kernel(IqnArgs a) {
     __shared__ float s_b[16];
     const int B = a.B, C = a.C;
     const int blk = blockIdx.x, tid = threadIdx.x;
+    if (a.act_rng && blk == 0 && tid == 0) *a.act_rng += a.act_inc;      // (the forward tiles run in the NEXT launch)
     if (blk >= 2 * B) {
         embed_extra_block(a, blk - 2 * B, s_b);      // defined in step_kernels.h (front_extra_block)
         return;

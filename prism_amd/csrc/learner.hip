@@ -766,7 +766,16 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
     a.cos_tiles = 0;          // (acting tiles draw and evaluate their basis themselves: no learner passes here)
     a.B = n;
     a.obs = a.next_obs = obs;
-    hipLaunchKernelGGL(iqn_embed_kernel, dim3(2 * n + front_extra_blocks(extra_dims(a))), dim3(256), 0, stream, a);
+    // quantile draws counted on the device (ld->rng_counters[2], added to `offset`): the call can be captured into a hipGraph
+    // and replayed -- the embed launch advances the counter by this call's n * n_tau draws, the tiles of the next launch
+    // start from counter - n * n_tau
+    const uint64_t act_inc = ld->dims.use_iqn ? (uint64_t)n * (uint64_t)n_tau : 0ull;
+    a.act_rng = (ld->rng_counters && !tau_in && act_inc) ? ld->rng_counters + 2 : nullptr;
+    a.act_inc = act_inc;
+    // PRISM_ACT_WEIGHTS_CURRENT: the stream-packed weight copies / LayerNorm helpers in the workspace were built from the
+    // parameters as they are now (by an earlier acting call since the last update): the launch is the n embeddings alone
+    const int extra = (ld->act_flags & PRISM_ACT_WEIGHTS_CURRENT) ? 0 : front_extra_blocks(extra_dims(a));
+    hipLaunchKernelGGL(iqn_embed_kernel, dim3((extra ? 2 * n : n) + extra), dim3(256), 0, stream, a);
     PRISM_CHECK_LAUNCH();
     if (ld->dims.n_heads > 0 && ld->dims.head_layers == 1) {
         // single-Linear DQN head: one workgroup per observation on the embeddings just written
@@ -778,8 +787,9 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
     a.B = n_pad;
     a.Bt = n;
     a.seed = seed;
-    a.offset = offset;
-    a.rng = nullptr;
+    a.offset = a.act_rng ? offset - act_inc : offset;
+    a.rng = a.act_rng ? ld->rng_counters + 1 : nullptr;      // (the tiles read word [1] of what they are given)
+    a.act_rng = nullptr;
     a.tau_out = nullptr;
     a.local_loss = 0;
     int np = 0, n_iqn = 0, n_q = 0;
@@ -849,23 +859,27 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
 // IDSActionSelector.generate_action_probs + select_action without random sampling (action_selectors.py:125-176).
 extern "C" int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
                                 int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
-                                float *out_aux, int64_t *out_action, prism_stream_t stream_) {
+                                float *out_aux, int64_t *out_action, int64_t *out_action_host, prism_stream_t stream_) {
     PRISM_CHECK_ARG(z && q && out_scores && out_action, "null buffers");
     PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_tau >= 1 && n_actions >= 1 && n_actions <= 16 && n_heads >= 1, "bad sizes");
-    IdsArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, lmbda, epsilon, rho_lower_bound, out_scores, out_aux, out_action};
-    hipLaunchKernelGGL(ids_score_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream_, k);
+    const int stage = n_tau * n_actions <= ACT_STAGE_MAX_FLOATS;
+    IdsArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, lmbda, epsilon, rho_lower_bound, out_scores, out_aux, out_action,
+              out_action_host, stage};
+    hipLaunchKernelGGL(ids_score_kernel, dim3(n), dim3(ACT_THREADS), stage ? (size_t)n_tau * n_actions * 4 : 0, (hipStream_t)stream_, k);
     PRISM_CHECK_LAUNCH();
     return PRISM_OK;
 }
 
 // GreedyActionSelector (action_selectors.py:70-83) on the buffers prism_act_forward filled.
 extern "C" int prism_greedy_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
-                                   int32_t n_heads, int64_t *out_action, float *out_mean, prism_stream_t stream_) {
+                                   int32_t n_heads, int64_t *out_action, float *out_mean, int64_t *out_action_host,
+                                   prism_stream_t stream_) {
     PRISM_CHECK_ARG((z || q) && out_action, "null buffers");
     PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_actions >= 1 && n_actions <= 16, "bad sizes");
     PRISM_CHECK_ARG(q ? n_heads >= 1 : n_tau >= 1, "bad sizes");
-    GreedyArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, out_action, out_mean};
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream_, k);
+    const int stage = !q && n_tau * n_actions <= ACT_STAGE_MAX_FLOATS;
+    GreedyArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, out_action, out_mean, out_action_host, stage};
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(n), dim3(ACT_THREADS), stage ? (size_t)n_tau * n_actions * 4 : 0, (hipStream_t)stream_, k);
     PRISM_CHECK_LAUNCH();
     return PRISM_OK;
 }

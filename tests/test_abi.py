@@ -46,7 +46,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
     assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4
     # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40), host_status
-    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 7 * 8 + 8 + 40 + 8
+    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 8 + 7 * 8 + 8 + 40 + 8
     assert ctypes.sizeof(N.DirectDesc) == 8 + 8 * 8 + 8 * 8 + 8 + 8 + 8 + 8
 
 

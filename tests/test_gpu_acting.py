@@ -64,7 +64,7 @@ def test_acting_matches_reference(dev, name, gemm_mode):
         action = torch.empty(n, dtype=torch.int64, device=dev)
         N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, cfg.ids_n_q_heads, cfg.ids_lambda,
                                          cfg.ids_epsilon, cfg.ids_rho_lower_bound, N.ptr(scores), N.ptr(aux), N.ptr(action),
-                                         N.current_stream_handle()), "prism_ids_select")
+                                         None, N.current_stream_handle()), "prism_ids_select")
         torch.cuda.synchronize()
         np.testing.assert_array_equal(action.cpu().numpy(), ref["action"])
         np.testing.assert_allclose(scores.cpu().numpy(), ref["ids/IDS Scores"], rtol=1e-3, atol=1e-6)
@@ -126,7 +126,7 @@ def test_ids_select_against_oracle_on_random_estimates(dev):
         scores = torch.empty((n, A), device=dev)
         action = torch.empty(n, dtype=torch.int64, device=dev)
         N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, heads, 0.1, 1e-10, 0.25, N.ptr(scores), None,
-                                         N.ptr(action), N.current_stream_handle()), "prism_ids_select")
+                                         N.ptr(action), None, N.current_stream_handle()), "prism_ids_select")
         torch.cuda.synchronize()
         if T == 1 or heads == 1:
             continue          # torch.var / torch.std of a single element are NaN in the reference too; only "does not fault"
@@ -208,3 +208,48 @@ def test_forward_selects_natively_also_in_pieces(dev, name):
     q, dist = agent.act_estimates(obs)
     g_sel = GreedyActionSelector()
     np.testing.assert_array_equal(act.cpu().numpy(), g_sel.select_action(g_sel.generate_action_probs(dist, q)).cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["full_small", "iqn_c3", "dqn_ln"])
+def test_forward_from_the_hipgraph_equals_the_eager_launches(dev, name):
+    """Agent.forward replayed from its hipGraph (the default: H2D of the observations, prism_act_forward, the selector kernel
+    and the D2H of the actions in one launch; quantile draws from the device counter rng_counters[2]) against the eager
+    launches on the same counters: the same actions call after call, from a host array, from a persistent device buffer
+    (the reference collector's pattern) and from fresh device tensors; ``.cpu()`` of the result is the graph's own copy."""
+    g, cfg, agent = updated_agent(name, dev)
+    C = int(g["C"])
+    rng = np.random.default_rng(3)
+    n = 5
+    assert agent.act_graph
+    frames = [(rng.random((n, 10, 10, C)) < 0.1).astype(np.float32) for _ in range(7)]
+    agent.act_graph = False
+    agent._act_draws = 777
+    want = [agent.forward(f).cpu().numpy().copy() for f in frames]
+    end_draws = agent._act_draws
+    agent.act_graph = True
+    # host arrays in
+    agent._act_draws = 777
+    got = [agent.forward(f) for f in frames]
+    assert type(got[-1]).__name__ == "_Actions" and got[-1].is_cuda and got[-1].dtype == torch.int64
+    agent._act_draws = 777
+    for i, f in enumerate(frames):
+        a = agent.forward(f)
+        np.testing.assert_array_equal(a.cpu().numpy(), want[i])             # the pinned copy of the graph's D2H node
+        np.testing.assert_array_equal(torch.Tensor.cpu(a.as_subclass(torch.Tensor)).numpy(), want[i])      # ... and the device tensor
+    assert agent._act_draws == end_draws
+    assert int(agent.rng_counters[2].item()) == end_draws                    # the device counter mirrors the host's
+    # one persistent device buffer in (read in place, keyed by its address)
+    buf = torch.zeros((n, 10, 10, C), device=dev)
+    agent._act_draws = 777
+    for i, f in enumerate(frames):
+        buf.copy_(torch.from_numpy(f))
+        np.testing.assert_array_equal(agent.forward(buf).cpu().numpy(), want[i])
+    # fresh device tensors every call (more than three addresses: staged through one device block)
+    agent._act_draws = 777
+    keep = []
+    for i, f in enumerate(frames):
+        t = torch.from_numpy(f).to(dev)
+        keep.append(t)
+        np.testing.assert_array_equal(agent.forward(t).cpu().numpy(), want[i])
+    assert any(k[2] == "dev" for k in agent._act_graphs)
+    assert any(st["g"] is not None for st in agent._act_graphs.values()), "no call was replayed from a graph"
