@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[i]; 2 = the metric's config")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-acting", action="store_true", help="skip the Agent.forward latency leg (profiling runs: its launches "
+                    "share kernel names with the learner's)")
     ap.add_argument("--repeats", type=int, default=0,
                     help="timed blocks of --steps steps (0: as many as fill --min-seconds of timed GPU work, at least 5)")
     ap.add_argument("--min-seconds", type=float, default=3.0,
@@ -450,7 +452,7 @@ def main():
                "roofline": roof}
         if dp_info:
             out["data_parallel"] = dp_info
-        if world == 1:
+        if world == 1 and not args.no_acting:
             # the loop's other half: one Agent.forward per update in the MinAtar presets -- host array in,
             # actions on the host out, replayed from its hipGraph; median over 300 calls each
             act = {}

@@ -60,9 +60,9 @@ constexpr int FW_CBS = 36;                       // row stride (dwords) of a bf1
 // LDS of a forward tile (floats): cos tile | tau + loss scalars | row-stat partials | K-slice partials | Z tile | head
 // weight; the loss of a mixed tile reuses the (folded, dead) K-slice partials for its two per-row products.
 // Phases: STREAM = prologue + streamed products, ROWS = fold / LayerNorm / head, LOSS = kind-2 tail.
-template <int H>
+template <int H, int WAVES = 8>
 struct FwLds {
-    static constexpr int W = fw_waves(H), HP = H + 4;
+    static constexpr int W = WAVES, HP = H + 4;
     static constexpr unsigned STREAM = 1u, ROWS = 2u, LOSS = 4u;
     // [16][CS] cos basis of the tile's rows (fp32 chain) | [3 planes][16 rows][FW_CBS] packed bf16 pieces (bf16 path)
     static constexpr LdsRegion COST{0, 3 * 16 * FW_CBS > 16 * CS ? 3 * 16 * FW_CBS : 16 * CS, STREAM};
@@ -78,8 +78,8 @@ struct FwLds {
     static_assert(lds_layout_ok(ALL, TOTAL), "forward tile: LDS regions live at the same time overlap");
     static_assert(COST.off % 4 == 0 && PART.off % 4 == 0 && W2S.off % 4 == 0 && HP % 4 == 0, "16-byte accessed regions");
 };
-template <int H>
-__host__ __device__ constexpr int fw_lds_floats() { return FwLds<H>::TOTAL; }
+template <int H, int WAVES = 8>
+__host__ __device__ constexpr int fw_lds_floats() { return FwLds<H, WAVES>::TOTAL; }
 
 // sum over the 32-lane half a lane belongs to; every lane of the half receives the total (fixed order)
 __device__ __forceinline__ float half_sum(float v) {
@@ -101,12 +101,19 @@ struct FwRow {           // what a lane needs to know about tile row m
     int64_t save;        // row index in the per-row save arrays, -1: not saved
 };
 
-template <int H, bool LN, bool SPLIT = false>
-__global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_value) {
+// WAVES = 4 (bf16 path, tile kinds 0 and 1): the same tile on a 256-thread workgroup, each wave streaming 256 columns.  Two such
+// workgroups fit one CU (51 KB of LDS, two waves per SIMD between them), so where a launch has several tiles per CU -- the
+// full model: 1152 tiles -- the prologue, fold and row phase of one tile run beside the weight stream of another instead of
+// in front of it (one 512-thread workgroup per CU leaves the matrix pipe and the L2 path idle for a third of every tile).
+template <int H, bool LN, bool SPLIT = false, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, 2) void fwd_tile_kernel(IqnArgs a_by_value) {      // (two waves per SIMD: 256 registers)
     kernarg_prefetch<sizeof(IqnArgs)>();
-    constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128, FW_WAVES = fw_waves(H), NTHREADS = fw_threads(H);
+    static_assert(WAVES == 8 || (WAVES == 4 && SPLIT && H == 128), "four-wave tiles: bf16 path at width 128");
+    constexpr int NHT = H / 16, HP = H + 4, KPT = H / 128, FW_WAVES = WAVES, NTHREADS = 64 * WAVES;
+    constexpr int ROW_PASSES = 512 / NTHREADS;       // the row phase handles 16 rows x 32 lanes: two passes of eight rows on four waves
+    constexpr int SPW = UV_SLICES / FW_WAVES;        // 128-column u slices per streaming wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef FwLds<H> LD;
+    typedef FwLds<H, WAVES> LD;
     float *cost = smem + LD::COST.off;           // [16][CS] cos basis of the tile's rows
     float *rowf = smem + LD::ROWF.off;           // [0,16) tau | [16,32) y | [32,48) q | [48,64) dq | [64,80) tau (loss order)
     float *stat = smem + LD::STAT.off;           // [3][8 waves][16 rows] shifted row sums / sums of squares / the shift
@@ -207,12 +214,13 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     if (kind != 1 && a.rng) rng_tau = ((const unsigned long long __attribute__((address_space(1))) *)a.rng)[1];
     // head Linear weight [A][H] and bias: the oldest requests of the kernel, so that waiting for them later
     // waits for nothing else (clamped indices: unconditional loads)
-    float w2r[H / 32], b2r;
+    constexpr int W2N = 16 * H / NTHREADS;
+    float w2r[W2N], b2r;
     {
         const gcf Ph = kind == 1 ? P + a.off.head_base + (int64_t)hd * a.off.head_stride : P;
         const gcf W2 = Ph + (kind == 1 ? a.off.h_w2 : a.off.iqn_w2), B2 = Ph + (kind == 1 ? a.off.h_b2 : a.off.iqn_b2);
 #pragma unroll
-        for (int i = 0; i < H / 32; ++i) w2r[i] = W2[min(tid + 512 * i, A * H - 1)];
+        for (int i = 0; i < W2N; ++i) w2r[i] = W2[min(tid + NTHREADS * i, A * H - 1)];
         b2r = B2[min(tid, A - 1)];
     }
 
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
 #pragma unroll
     for (int i = 0; i < NHT; ++i) accT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s1 = 0.f, s2 = 0.f, cshift = 0.f;
-    static_assert(!LN || FW_WAVES == UV_SLICES, "one u slice per streaming wave");
+    static_assert(UV_SLICES % FW_WAVES == 0, "whole u slices per streaming wave");
 
     // ---------------------------------------------------------------------------------------------
     // the streamed products.  PHI: IQN rows (phi product feeds the trunk product); !PHI: Q-head rows.
@@ -262,8 +270,8 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         }
         // the head Linear of the row phase (requested first of all): parked in LDS, read after the fold
 #pragma unroll
-        for (int i = 0; i < H / 32; ++i)
-            if (tid + 512 * i < A * H) w2s[tid + 512 * i] = w2r[i];
+        for (int i = 0; i < W2N; ++i)
+            if (tid + NTHREADS * i < A * H) w2s[tid + NTHREADS * i] = w2r[i];
         if (tid < A) rowf[96 + tid] = b2r;
 
         f32x4 cosB[4];
@@ -408,24 +416,30 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     // ---------------------------------------------------------------------------------------------
     auto stream_split = [&](auto phi_tag) __attribute__((always_inline)) {
         constexpr bool PHI = decltype(phi_tag)::value;
-        constexpr int G = (PHI ? 4 : 0) + NHT, P0 = PHI ? 4 : 0, NDS = 4, RW = FW_SPLIT_RING, NQ = NDS * NHT, NP = NDS * 4;
+        constexpr int G = (PHI ? 4 : 0) + NHT, P0 = PHI ? 4 : 0, NDS = 32 / FW_WAVES, RW = FW_SPLIT_RING, NQ = NDS * NHT, NP = NDS * 4;
+        constexpr int WCOLS = E_DIM / FW_WAVES;          // embed columns of a wave
         typedef const u32x4 __attribute__((address_space(1))) *gcu4;
         typedef const f32x4 __attribute__((address_space(1))) *gcf4;
         const gcu4 wp = reinterpret_cast<gcu4>(ps_wpk) + (kind == 1 ? (size_t)hd * (32 * NHT * 3 * 64) : (size_t)0) +
-                        (size_t)(4 * w) * G * 3 * 64 + lane;
+                        (size_t)(NDS * w) * G * 3 * 64 + lane;
         auto slot = [&](int ds, int group, int plane) __attribute__((always_inline)) { return wp[((ds * G + group) * 3 + plane) * 64]; };
         constexpr bool KO_HALF = (FW_KO & 4) != 0;      // (wrong numbers: the second half of the stream re-uses stale operand registers)
-        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + 128 * w + 4 * g;
-        const gcf brow = P + a.off.phi_b + 128 * w + 4 * g;
+        const gcf erow = e_base + (int64_t)myrow.b * E_DIM + WCOLS * w + 4 * g;
+        const gcf brow = P + a.off.phi_b + WCOLS * w + 4 * g;
         // prepared quantile samples + basis pieces of this tile (cos_basis_block): the first requests of the stream
         const unsigned int __attribute__((address_space(1))) *cpk =
             PHI ? (const unsigned int __attribute__((address_space(1))) *)pp->cospk : nullptr;
-        unsigned int c_h = 0, c_m = 0, c_l = 0, tbits = 0;
+        unsigned int c_h[ROW_PASSES], c_m[ROW_PASSES], c_l[ROW_PASSES], tbits = 0;
+#pragma unroll
+        for (int u = 0; u < ROW_PASSES; ++u) c_h[u] = c_m[u] = c_l[u] = 0;
         if (PHI && cpk) {
-            const unsigned int __attribute__((address_space(1))) *blk = cpk + (size_t)tile * CP_TILE + (tid >> 5) * 32 + (tid & 31);
-            c_h = blk[0];
-            c_m = blk[16 * 32];
-            c_l = blk[2 * 16 * 32];
+            const unsigned int __attribute__((address_space(1))) *blk = cpk + (size_t)tile * CP_TILE + tid;
+#pragma unroll
+            for (int u = 0; u < ROW_PASSES; ++u) {
+                c_h[u] = blk[NTHREADS * u];
+                c_m[u] = blk[16 * 32 + NTHREADS * u];
+                c_l[u] = blk[2 * 16 * 32 + NTHREADS * u];
+            }
             if (tid < 16) tbits = cpk[(size_t)tile * CP_TILE + 3 * 16 * 32 + tid];
         }
         u32x4 wph[2][3], w1r[RW][3];
@@ -447,19 +461,21 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             for (int pl = 0; pl < 3; ++pl) w1r[q][pl] = slot(0, P0 + q, pl);
         // the head Linear of the row phase (requested first of all): parked in LDS, read after the fold
 #pragma unroll
-        for (int i = 0; i < H / 32; ++i)
-            if (tid + 512 * i < A * H) w2s[tid + 512 * i] = w2r[i];
+        for (int i = 0; i < W2N; ++i)
+            if (tid + NTHREADS * i < A * H) w2s[tid + NTHREADS * i] = w2r[i];
         if (tid < A) rowf[96 + tid] = b2r;
 
         unsigned int *cosp = reinterpret_cast<unsigned int *>(cost);       // [3][16][FW_CBS] dwords of bf16 pairs
         if (PHI && cpk) {
             // quantile samples and basis pieces prepared by the embed / front launch (cos_basis_block): one round of loads
             // and one barrier where the tile's own draw + cosines + split were 7 k cycles in front of its first MFMA
-            static_assert(NTHREADS == 512, "one basis pair per thread");
-            const int m = tid >> 5, kp = tid & 31;
-            cosp[(0 * 16 + m) * FW_CBS + kp] = c_h;
-            cosp[(1 * 16 + m) * FW_CBS + kp] = c_m;
-            cosp[(2 * 16 + m) * FW_CBS + kp] = c_l;
+#pragma unroll
+            for (int u = 0; u < ROW_PASSES; ++u) {
+                const int idx = tid + NTHREADS * u, m = idx >> 5, kp = idx & 31;          // one basis pair per (thread, pass)
+                cosp[(0 * 16 + m) * FW_CBS + kp] = c_h[u];
+                cosp[(1 * 16 + m) * FW_CBS + kp] = c_m[u];
+                cosp[(2 * 16 + m) * FW_CBS + kp] = c_l[u];
+            }
             if (tid < 16) rowf[tid] = __uint_as_float(tbits);
             lds_barrier();
         } else if (PHI) {
@@ -480,11 +496,11 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                 rowf[tid] = tau;
             }
             lds_barrier();
-            {
-                // thread = (row m, basis pair k0, k0 + 1): the cos values as torch computes them (iqn_model.py:90-92), saved in
-                // fp32 for the backward launch, and their three bf16 pieces parked as the B operand of the phi product
-                static_assert(NTHREADS == 512, "one basis pair per thread");
-                const int m = tid >> 5, k0 = 2 * (tid & 31);
+#pragma unroll
+            for (int u = 0; u < ROW_PASSES; ++u) {
+                // (thread, pass) = (row m, basis pair k0, k0 + 1): the cos values as torch computes them (iqn_model.py:90-92), saved
+                // in fp32 for the backward launch, and their three bf16 pieces parked as the B operand of the phi product
+                const int idx = tid + NTHREADS * u, m = idx >> 5, k0 = 2 * (idx & 31);
                 const float tm = rowf[m];
                 const float c0 = cosf((tm * (float)(k0 + 1)) * PI_F), c1 = cosf((tm * (float)(k0 + 2)) * PI_F);
                 const FwRow r = row_of(m);
@@ -496,9 +512,9 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
                 const float ra = c0 - __uint_as_float(h << 16), rb = c1 - __uint_as_float(h & 0xffff0000u);
                 const unsigned int md = pack_bf16(ra, rb);
                 const float sa = ra - __uint_as_float(md << 16), sb = rb - __uint_as_float(md & 0xffff0000u);
-                cosp[(0 * 16 + m) * FW_CBS + (tid & 31)] = h;
-                cosp[(1 * 16 + m) * FW_CBS + (tid & 31)] = md;
-                cosp[(2 * 16 + m) * FW_CBS + (tid & 31)] = pack_bf16(sa, sb);
+                cosp[(0 * 16 + m) * FW_CBS + (idx & 31)] = h;
+                cosp[(1 * 16 + m) * FW_CBS + (idx & 31)] = md;
+                cosp[(2 * 16 + m) * FW_CBS + (idx & 31)] = pack_bf16(sa, sb);
             }
             lds_barrier();
         }
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         Split3 xs;
         float *const phi_dst = (PHI && myrow.save >= 0)
-                                   ? a.ws.phis + ((myrow.save >> 4) * (int64_t)(E_DIM / 16) + 8 * w) * 256 + (myrow.save & 15) * 16 + 4 * g
+                                   ? a.ws.phis + ((myrow.save >> 4) * (int64_t)(E_DIM / 16) + (WCOLS / 16) * w) * 256 + (myrow.save & 15) * 16 + 4 * g
                                    : nullptr;
         // (ReLU(phi) for the backward launch goes out from inside the stream, 16 bytes per lane and n-tile.  Knock-out, same
         // box: without these stores the tile takes 20.9 instead of 22.4 us -- but parking the values in LDS and storing them
@@ -594,7 +610,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         }
     };
     if constexpr (SPLIT) {
-        static_assert(H == 128 && FW_WAVES == 8, "the bf16 path is laid out for width 128, eight streaming waves");
+        static_assert(H == 128 && (FW_WAVES == 8 || FW_WAVES == 4), "the bf16 path is laid out for width 128, eight or four streaming waves");
         if (kind == 1) stream_split(std::false_type{});
         else stream_split(std::true_type{});
     } else
@@ -612,16 +628,15 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     }
     PRISM_STAMP(2);
 
-    // ---- fold the eight K-slices ------------------------------------------------------------------
-    const int fm = tid >> 5, fc = tid & 31;          // fold / row phase: row fm, hidden units 4 fc .. 4 fc + 3 (+128)
-    const FwRow frow = row_of(fm);
+    // ---- fold the K-slices ------------------------------------------------------------------------
+    const int fc = tid & 31;                         // fold / row phase: hidden units 4 fc .. 4 fc + 3 (+128) of row fm
     // operands of the row phase: requested now, consumed after the barrier
     const gcf Ptr = kind == 1 ? P + a.off.head_base + (int64_t)hd * a.off.head_stride : P;
     const int64_t o_b1 = kind == 1 ? a.off.h_b1 : a.off.iqn_b1, o_g2 = kind == 1 ? a.off.h_ln2_g : a.off.iqn_ln2_g;
     const int64_t o_be2 = kind == 1 ? a.off.h_ln2_b : a.off.iqn_ln2_b;
     const bool al = kind != 1;                       // head tensors are only 4-byte aligned
     const gcf uvp = ps_uv + (kind == 1 ? (size_t)hd * UV_ROWS * H : (size_t)0);
-    f32x4 u4[KPT], vb4[KPT], g24[KPT], be24[KPT], us4[LN ? UV_SLICES : 1][KPT];
+    f32x4 u4[KPT], vb4[KPT], g24[KPT], be24[KPT], us4[LN ? FW_WAVES : 1][KPT];      // us4[w]: u over the columns wave w streamed
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int h0 = 128 * k + 4 * fc;
@@ -630,7 +645,12 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             u4[k] = ld4(uvp + h0, true);
             vb4[k] = ld4(uvp + H + h0, true) + bb;
 #pragma unroll
-            for (int ww = 0; ww < UV_SLICES; ++ww) us4[LN ? ww : 0][k] = ld4(uvp + (2 + ww) * H + h0, true);
+            for (int ww = 0; ww < FW_WAVES; ++ww) {
+                f32x4 t = ld4(uvp + (2 + SPW * ww) * H + h0, true);
+#pragma unroll
+                for (int sl = 1; sl < SPW; ++sl) t += ld4(uvp + (2 + SPW * ww + sl) * H + h0, true);
+                us4[LN ? ww : 0][k] = t;
+            }
             g24[k] = ld4(Ptr + o_g2 + h0, al);
             be24[k] = ld4(Ptr + o_be2 + h0, al);
         } else {
@@ -658,30 +678,44 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
     lds_barrier();
     PRISM_STAMP(3);
 
-    float mean1 = 0.f, rstd1 = 1.f;
-    float cdev[LN ? UV_SLICES : 1];            // c_w - mean of this row: what multiplies the slice sums u_w below
-    if (LN) {
-        // shifted moments of the eight K slices (128 elements each): mean_w = c_w + s1_w / 128, M2_w = s2_w - s1_w^2 / 128;
-        // whole row: mean = avg(mean_w), M2 = sum M2_w + 128 sum (mean_w - mean)^2
-        constexpr float NW = (float)(E_DIM / UV_SLICES);
-        float cw[UV_SLICES], a1[UV_SLICES], a2[UV_SLICES], cbar = 0.f, t1 = 0.f;
+    // The row phase: one row per 32-lane half-wave -- all sixteen at once on eight waves, two passes of eight on four.
+    // (What the loss tail of a mixed tile reads of it -- pre, hx, rstd2, frow, fm of EVERY row at once -- only exists with
+    // ROW_PASSES == 1: mixed tiles run on eight waves.)
+    float pre[4 * KPT], hx[4 * KPT];           // pre-activation / what feeds the head Linear (xhat2 with LN, ReLU(pre) without)
+    float rstd2 = 1.f;
+    int fm = tid >> 5;
+    FwRow frow = row_of(fm);
+    const bool local_loss = kind == 2;
 #pragma unroll
-        for (int ww = 0; ww < UV_SLICES; ++ww) {
+    for (int rp = 0; rp < ROW_PASSES; ++rp) {
+    if (rp > 0) {
+        fm = (tid >> 5) + (NTHREADS / 32) * rp;
+        frow = row_of(fm);
+    }
+    float mean1 = 0.f, rstd1 = 1.f;
+    float cdev[LN ? FW_WAVES : 1];             // c_w - mean of this row: what multiplies the slice sums u_w below
+    if (LN) {
+        // shifted moments of the K slices (NW elements each): mean_w = c_w + s1_w / NW, M2_w = s2_w - s1_w^2 / NW;
+        // whole row: mean = avg(mean_w), M2 = sum M2_w + NW sum (mean_w - mean)^2
+        constexpr float NW = (float)(E_DIM / FW_WAVES);
+        float cw[FW_WAVES], a1[FW_WAVES], a2[FW_WAVES], cbar = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < FW_WAVES; ++ww) {
             a1[ww] = stat[ww * 16 + fm];
             a2[ww] = stat[(FW_WAVES + ww) * 16 + fm];
             cw[ww] = stat[(2 * FW_WAVES + ww) * 16 + fm];
         }
 #pragma unroll
-        for (int ww = 0; ww < UV_SLICES; ++ww) {
+        for (int ww = 0; ww < FW_WAVES; ++ww) {
             cbar += cw[ww];
             t1 += a1[ww];
         }
-        cbar *= 1.0f / UV_SLICES;
+        cbar *= 1.0f / FW_WAVES;
         const float dmean = t1 * (1.0f / E_DIM);          // mean - cbar
         mean1 = cbar + dmean;
         float m2 = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < UV_SLICES; ++ww) {
+        for (int ww = 0; ww < FW_WAVES; ++ww) {
             const float dw = (cw[ww] - cbar) + (a1[ww] * (1.0f / NW) - dmean);      // mean_w - mean
             m2 += (a2[ww] - a1[ww] * a1[ww] * (1.0f / NW)) + NW * (dw * dw);
             cdev[LN ? ww : 0] = (cw[ww] - cbar) - dmean;
@@ -693,7 +727,6 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             (kind == 1 ? a.ws.q_rstd1 : a.ws.rstd1)[frow.save] = rstd1;
         }
     }
-    float pre[4 * KPT], hx[4 * KPT];           // pre-activation / what feeds the head Linear (xhat2 with LN, ReLU(pre) without)
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
         const int h0 = 128 * k + 4 * fc;
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             for (int c = 0; c < 4; ++c) {
                 float t = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < UV_SLICES; ++ww) t = fmaf(cdev[LN ? ww : 0], us4[LN ? ww : 0][k][c], t);
+                for (int ww = 0; ww < FW_WAVES; ++ww) t = fmaf(cdev[LN ? ww : 0], us4[LN ? ww : 0][k][c], t);
                 sv[c] += t;
             }
         }
@@ -718,7 +751,7 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
         for (int c = 0; c < 4; ++c) pre[4 * k + c] = LN ? rstd1 * sv[c] + vb4[k][c] : sv[c] + vb4[k][c];
     }
     // ---- ReLU -> [LayerNorm(H)] -> head --------------------------------------------------------------
-    float rstd2 = 1.f;
+    rstd2 = 1.f;
     {
         float hs = 0.f;
 #pragma unroll
@@ -739,7 +772,6 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             for (int i = 0; i < 4 * KPT; ++i) hx[i] *= rstd2;
         }
     }
-    const bool local_loss = kind == 2;
     if (frow.save >= 0 && !local_loss) {
         // saved for the loss / backward launches: pre-activation and the head Linear's input
         float *sp = (kind == 1 ? a.ws.q_pre1 : a.ws.pre1) + frow.save * H, *sx = (kind == 1 ? a.ws.q_xhat2 : a.ws.xhat2) + frow.save * H;
@@ -780,8 +812,10 @@ __global__ __launch_bounds__(fw_threads(H)) void fwd_tile_kernel(IqnArgs a_by_va
             zo[zr * A + fc] = zmine;
         }
     }
+    }      // row passes
     PRISM_STAMP(4);
     if (!local_loss) return;
+    if constexpr (ROW_PASSES != 1) return;           // (mixed tiles are launched on eight waves only)
 
     // =================================================================================================
     // kind 2: the loss of the tile's samples (iqn_model.py:95-201), then head + LayerNorm backward of their

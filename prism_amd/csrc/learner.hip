@@ -498,6 +498,31 @@ static hipError_t set_max_lds(const void *fn, size_t bytes) {
     return e;
 }
 
+static int device_cus() {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cache[dev] = cus;
+}
+
+// Forward tiles on four waves (fwd_kernels.h, WAVES = 4: two 256-thread workgroups per CU, the latency-bound phases of one tile
+// beside the weight stream of another): where the launch has at least two tiles per CU and no mixed tile (their loss tail
+// needs all sixteen rows in registers at once).  PRISM_FWD_WAVES=8 / 4 forces a form (A/B runs).
+static bool fwd_four_waves(const IqnArgs &aa, int tiles) {
+    if (!aa.split) return false;
+    for (int i = 0; i < aa.n_pass; ++i)
+        if (aa.pass[i].kind == 2) return false;
+    static const int forced = [] { const char *e = getenv("PRISM_FWD_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 8) return false;
+    if (forced == 4) return true;
+    return tiles >= 2 * device_cus();
+}
+
 // ---- the post launch: gradient slabs / small tensors / conv fold (+ priority writeback block); with `tail` also the
 // clip + Adam update behind a grid barrier (single GPU) ------------------------------------------------------------
 // workgroups of the fused-tail instantiation `dense` that fit the CURRENT device at once (per device: processes that
@@ -594,6 +619,13 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
                 constexpr bool LL = decltype(l)::value;
                 const size_t lds = fw_lds_floats<HH>() * sizeof(float);
                 if constexpr (HH == 128) {
+                    if (aa.split && fwd_four_waves(aa, tiles)) {
+                        const size_t lds4 = fw_lds_floats<HH, 4>() * sizeof(float);
+                        herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true, 4>, lds4);
+                        if (herr == hipSuccess)
+                            hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true, 4>), dim3(tiles), dim3(256), lds4, stream, aa);
+                        return;
+                    }
                     if (aa.split) {
                         herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
                         if (herr == hipSuccess)
@@ -827,6 +859,13 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
             constexpr bool LL = decltype(l)::value;
             const size_t lds = fw_lds_floats<HH>() * sizeof(float);
             if constexpr (HH == 128) {
+                if (aa.split && fwd_four_waves(aa, tiles)) {
+                    const size_t lds4 = fw_lds_floats<HH, 4>() * sizeof(float);
+                    herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true, 4>, lds4);
+                    if (herr == hipSuccess)
+                        hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true, 4>), dim3(tiles), dim3(256), lds4, stream, aa);
+                    return;
+                }
                 if (aa.split) {
                     herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
                     if (herr == hipSuccess)

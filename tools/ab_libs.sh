@@ -6,7 +6,7 @@ FLAGS=$1; N=$2; shift 2
 for i in $(seq $N); do
   for lib in "$@"; do
     if [ "$lib" = tree ]; then unset PRISM_HIP_LIB; else export PRISM_HIP_LIB=$(realpath $lib); fi
-    python3 $R/bench.py --steps 2000 --warmup 100 --repeats 5 --no-cpu-baseline $FLAGS 2>/dev/null | python3 -c "
+    python3 $R/bench.py --steps 2000 --warmup 100 --repeats 5 --no-cpu-baseline --no-acting $FLAGS 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.readline()); print('$lib', d['ms_per_step'], d['roofline']['kernel_us_event_incl_boundary'])"
   done
 done

@@ -3,6 +3,6 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 FLAGS=$1; shift
 for e in "" "$@"; do
-  env $e python3 $R/bench.py --steps 500 --warmup 50 --repeats 2 --no-cpu-baseline $FLAGS 2>/dev/null | python3 -c "
+  env $e python3 $R/bench.py --steps 500 --warmup 50 --repeats 2 --no-cpu-baseline --no-acting $FLAGS 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.readline()); print('[$e]', d['ms_per_step'], d['roofline']['kernel_us_event_incl_boundary'])"
 done

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/ks_$1
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 1000 --warmup 100 --repeats 2 --no-cpu-baseline ${@:2} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 1000 --warmup 100 --repeats 2 --no-cpu-baseline --no-acting ${@:2} > $OUT/run.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete
 python3 - $OUT $1 <<'P'
 import csv, glob, sys

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-graph --profile-steps 0 --repeats 1 ${@:3} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $OUT -- python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-acting --no-graph --profile-steps 0 --repeats 1 ${@:3} > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = sorted(glob.glob("$OUT/*/*counter_collection.csv"))[0]
