@@ -436,7 +436,14 @@ __global__ __launch_bounds__(256) void step_front_kernel(IqnArgs a, prism_replay
 // one thread per float4 of the slab; two (adjacent lanes, eight chunks each) when the backward wrote sixteen row chunks
 __host__ __device__ inline int post_slab_blocks(int slab, int n_chunks = 8) { return ((slab / 4) * (n_chunks > 8 ? 2 : 1) + 1023) / 1024; }
 __host__ __device__ inline int post_small_blocks(int H) { return H / SMALL_W; }     // 16 hidden units per block
-__host__ __device__ inline int post_q_slab_blocks(int n_heads, int q_slab) { return (n_heads * (q_slab / 4) + 1023) / 1024; }
+// Q-head slabs (one per head: no row chunks to add up, only the Theil term and the norm partial): a float4 per thread and
+// trip, at most POST_Q_SLAB_MAX workgroups -- ten heads were 326 workgroups of one trip, which alone kept the launch (640
+// workgroups, 2.5 rounds of the CUs) from being resident at once, i.e. from carrying the fused tail
+constexpr int POST_Q_SLAB_MAX = 64;
+__host__ __device__ inline int post_q_slab_blocks(int n_heads, int q_slab) {
+    const int full = (n_heads * (q_slab / 4) + 1023) / 1024;
+    return full < POST_Q_SLAB_MAX ? full : POST_Q_SLAB_MAX;
+}
 __host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd, int slab, int q_slab, int Hi,
                                            int Hq, int n_chunks = 8) {
     int n = conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
@@ -1029,8 +1036,9 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             }
             const int nqs = post_q_slab_blocks(a.n_heads, a.q_slab), nqsm = post_small_blocks(a.Hq);
             if (blk < nqs) {
-                const int64_t i = (int64_t)blk * 1024 + tid;
-                if (i < (int64_t)a.n_heads * (a.q_slab / 4)) q_slab_sum(a, i, kappa, sq);
+                const int64_t n4 = (int64_t)a.n_heads * (a.q_slab / 4);
+#pragma unroll 2
+                for (int64_t i = (int64_t)blk * 1024 + tid; i < n4; i += (int64_t)nqs * 1024) q_slab_sum(a, i, kappa, sq);
             } else {
                 const int x = blk - nqs;
                 // total loss (agent.py:58-64): mean(dl*w) + mean(ql*w); operands requested before the fold
