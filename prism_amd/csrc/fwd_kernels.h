@@ -610,7 +610,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fwd_tile_kernel(IqnArgs a_by_va
         }
     };
     if constexpr (SPLIT) {
-        static_assert(H == 128 && (FW_WAVES == 8 || FW_WAVES == 4), "the bf16 path is laid out for width 128, eight or four streaming waves");
+        static_assert((H == 128 && (FW_WAVES == 8 || FW_WAVES == 4)) || (H == 256 && FW_WAVES == 8),
+                      "the bf16 path: width 128 on eight or four streaming waves, width 256 on eight");
         if (kind == 1) stream_split(std::false_type{});
         else stream_split(std::true_type{});
     } else

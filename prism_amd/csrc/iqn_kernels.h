@@ -1096,84 +1096,119 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
 // ------------------------------------------------------------------------------------------
 // Block routines of the post kernel (step_kernels.h): conv-backward partials and the small tensors.
 // ------------------------------------------------------------------------------------------
-constexpr int CONV_SPB = 4;              // samples per conv-backward block
 constexpr int CONV_ROW = 16 * 90 + 16;   // floats per partial row: 16 * 9C weights (C <= 10) + 16 biases
 constexpr int SMALL_MAX_B = 4096;
 
-// d conv_w / d conv_b partial sums over samples [cb*CONV_SPB, ...) for all 16 output channels.
-// lds: CONV_LDS_FLOATS floats: obs [CONV_SPB][1000] | dconv [CONV_SPB][16*65] | partials.  1024 threads.
-// Work item = (sample, out channel c, in channel ci, kernel row dy): its three dx outputs share every
-// LDS operand (10 observation values + 8 gradient values per image row feed 24 MACs).
-constexpr int CONV_LDS_FLOATS = CONV_SPB * (1000 + 16 * 65) + CONV_SPB * 16 * 10 * 3 * 3;
-constexpr LdsRegion CV_OBS{0, CONV_SPB * 1000, LDS_ALWAYS}, CV_DC{CONV_SPB * 1000, CONV_SPB * 16 * 65, LDS_ALWAYS};
-constexpr LdsRegion CV_PAR{CONV_SPB * (1000 + 16 * 65), CONV_SPB * 16 * 10 * 3 * 3, LDS_ALWAYS};     // (c, ci, dy) x 3 per sample, C <= 10
-constexpr LdsRegion CV_REGIONS[] = {CV_OBS, CV_DC, CV_PAR};
-static_assert(lds_layout_ok(CV_REGIONS, CONV_LDS_FLOATS), "conv backward block: LDS regions overlap");
-// (Measured and not kept: the staging with every operand requested up front -- one round of loads instead of three, -0.8 us
-// on c4's post launch once its long roles start first, but with it in the library c3's front launch runs 0.5 us longer,
-// same-box A/B, four alternations; the cause was not found.)
+// d conv_w / d conv_b partial sums over the samples of block cb, all 16 output channels, on the matrix core.
+// (minatar_cnn_model.py:43-46 backward: dW[c][k] = sum_b sum_pos dconv[b][c][pos] * patch[b][pos][k], k = (ci, dy, dx);
+// db[c] = sum_b sum_pos dconv[b][c][pos].)  That is a [16 x 64 B] x [64 B x 9C] product: per sample sixteen K steps (four
+// positions each) of v_mfma_f32_16x16x4_f32 per 16-column tile of k, accumulated across the samples in the matrix core's
+// registers; the bias gradient is one more column of the patch matrix (k = 9C, all ones: 9C is never a multiple of 16 for
+// C <= 10).  A wave owns one k tile and every G-th sample of the block (G = 16 / tiles wave groups); the G partial tiles are
+// added through LDS in group order.  Staging is ONE round of loads: every operand of the block's samples is requested before
+// the first is used (observations as float4 into the channel-major image the forward convolution uses, the ReLU-masked
+// embedding gradient as float4 of d e (IQN) + the Q heads' slots in fixed order).
+// (Round 3's form -- one (sample, c, ci, dy) item a thread, fmaf chains out of LDS, four samples a block -- took 34 k cycles
+// a block on c4, 11.6 k of them four dependent staging trips: the longest role of its post launch.)
+__host__ __device__ constexpr int conv_spb(int C) { return C <= 5 ? 8 : 4; }          // samples per conv-backward block
+constexpr int CV_DCS = 68;                                                              // row stride of a sample's [16][64] gradient image
+__host__ __device__ constexpr int conv_sample_floats(int C) { return 100 * C + 16 * CV_DCS; }
+constexpr int CONV_LDS_FLOATS = 8 * conv_sample_floats(5) > 4 * conv_sample_floats(10) ? 8 * conv_sample_floats(5) : 4 * conv_sample_floats(10);
+static_assert(conv_spb(5) * conv_sample_floats(5) <= CONV_LDS_FLOATS && conv_spb(10) * conv_sample_floats(10) <= CONV_LDS_FLOATS &&
+              16 * 256 <= CONV_LDS_FLOATS, "conv backward block: samples + reduction scratch fit the pool");
 __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb, float *lds) {
-    float *s_obs = lds + CV_OBS.off, *s_dc = lds + CV_DC.off, *s_par = lds + CV_PAR.off;
     const int tid = threadIdx.x, B = a.B, C = a.C;
-    const int b0 = cb * CONV_SPB, ns = min(CONV_SPB, B - b0);
-#pragma unroll 2
-    for (int i = tid; i < ns * 100 * C; i += 1024) {
-        const int s = i / (100 * C), o = i - s * 100 * C;
-        s_obs[s * 1000 + o] = a.obs[(int64_t)(b0 + s) * 100 * C + o];
-    }
-#pragma unroll 2
-    for (int i = tid; i < ns * E_DIM; i += 1024) {
-        const int s = i >> 10, n = i & 1023;
-        const int64_t o = (int64_t)(b0 + s) * E_DIM + n;
-        float d = (a.use_iqn && a.propagate_grad) ? a.ws.de_iqn[o] : 0.f;
-        float dh[16];                                    // every head's value requested before the first add
+    const int SPB = conv_spb(C), SF = conv_sample_floats(C);
+    const int b0 = cb * SPB, ns = min(SPB, B - b0);
+    // ---- staging: one round of loads
+    {
+        // observations: float4 t of sample s (25 C per sample; SPB * 25 C <= 1024)
+        const int per = 25 * C, so = tid / per, to = tid - so * per;
+        const bool ob_ok = so < ns;
+        float4 ov = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ob_ok) ov = reinterpret_cast<const float4 *>(a.obs + (int64_t)(b0 + so) * 100 * C)[to];
+        // embedding gradient: float4 n4 of sample s, two per thread at eight samples a block
+        const bool iq = a.use_iqn && a.propagate_grad;
+        float4 di[2], ev[2], q0[2], q1[2];
+        bool ok[2];
 #pragma unroll
-        for (int hd = 0; hd < 16; ++hd) dh[hd] = hd < a.q_de_slots ? a.ws.de_q[(size_t)hd * B * E_DIM + o] : 0.f;
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 1024 * it, sm = idx >> 8, n4 = idx & 255;
+            ok[it] = sm < ns;
+            const int64_t o = ((int64_t)(b0 + (ok[it] ? sm : 0)) * E_DIM) / 4 + n4;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            di[it] = iq ? reinterpret_cast<const float4 *>(a.ws.de_iqn)[o] : z;
+            ev[it] = reinterpret_cast<const float4 *>(a.ws.e_cur)[o];
+            q0[it] = a.q_de_slots > 0 ? reinterpret_cast<const float4 *>(a.ws.de_q)[o] : z;
+            q1[it] = a.q_de_slots > 1 ? reinterpret_cast<const float4 *>(a.ws.de_q + (size_t)B * E_DIM)[o] : z;
+        }
+        if (ob_ok) obs_to_lds(lds + so * SF, ov, to, C);
 #pragma unroll
-        for (int hd = 0; hd < 16; ++hd)
-            if (hd < a.q_de_slots) d += dh[hd];          // slots in fixed order
-        s_dc[s * (16 * 65) + (n >> 6) * 65 + (n & 63)] = a.ws.e_cur[o] > 0.f ? d : 0.f;
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 1024 * it, sm = idx >> 8, n4 = idx & 255;
+            if (!ok[it]) continue;
+            float d[4] = {di[it].x, di[it].y, di[it].z, di[it].w};
+            if (a.q_de_slots > 0) { d[0] += q0[it].x; d[1] += q0[it].y; d[2] += q0[it].z; d[3] += q0[it].w; }
+            if (a.q_de_slots > 1) { d[0] += q1[it].x; d[1] += q1[it].y; d[2] += q1[it].z; d[3] += q1[it].w; }
+            // (more slots -- one per head where the two-GEMM backward does not apply: two per trip, slots in fixed order)
+            for (int hd = 2; hd < a.q_de_slots; hd += 2) {
+                const int64_t o = ((int64_t)(b0 + sm) * E_DIM) / 4 + n4;
+                const float4 u = reinterpret_cast<const float4 *>(a.ws.de_q + (size_t)hd * B * E_DIM)[o];
+                const float4 v = hd + 1 < a.q_de_slots ? reinterpret_cast<const float4 *>(a.ws.de_q + (size_t)(hd + 1) * B * E_DIM)[o]
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[0] += u.x; d[1] += u.y; d[2] += u.z; d[3] += u.w;
+                if (hd + 1 < a.q_de_slots) { d[0] += v.x; d[1] += v.y; d[2] += v.z; d[3] += v.w; }
+            }
+            const float e4[4] = {ev[it].x, ev[it].y, ev[it].z, ev[it].w};
+            const int n = 4 * n4;
+            float4 m;
+            m.x = e4[0] > 0.f ? d[0] : 0.f;
+            m.y = e4[1] > 0.f ? d[1] : 0.f;
+            m.z = e4[2] > 0.f ? d[2] : 0.f;
+            m.w = e4[3] > 0.f ? d[3] : 0.f;
+            *reinterpret_cast<float4 *>(lds + sm * SF + 100 * C + (n >> 6) * CV_DCS + (n & 63)) = m;
+        }
     }
     __syncthreads();
     PRISM_STAMP(22);
-    const int per_s = 16 * C * 3;                 // (c, ci, dy) groups per sample
-    for (int item = tid; item < ns * per_s; item += 1024) {
-        const int s = item / per_s, og = item - s * per_s;
-        const int c = og / (3 * C), r = og - c * 3 * C, ci = r / 3, dy = r - ci * 3;
-        const float *dc = &s_dc[s * (16 * 65) + c * 65];
-        const float *ob = &s_obs[s * 1000 + dy * 10 * C + ci];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // ---- the product: wave = (sample group grp, k tile nt)
+    const int K = 9 * C, NT = (K + 1 + 15) >> 4, G = 16 / NT;
+    const int w = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int nt = w % NT, grp = w / NT;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (grp < G) {
+        const int k = 16 * nt + li, kc = k < K ? k : K - 1;
+        const int ci = (kc * 7282) >> 16, t9 = kc - 9 * ci, dy = (t9 * 11) >> 5;      // kc / 9, t9 / 3 (kc < 1000)
+        const int koff = ci * 100 + dy * 10 + (t9 - 3 * dy) + g;
+        const float kone = k == K ? 1.f : 0.f;
+        for (int s = grp; s < ns; s += G) {
+            const float *ob = lds + s * SF + koff, *dc = lds + s * SF + 100 * C + li * CV_DCS + g;
+            float av[16], bv[16];
 #pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            float row[10];
-#pragma unroll
-            for (int x = 0; x < 10; ++x) row[x] = ob[(y * 10 + x) * C];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float d = dc[y * 8 + x];
-                a0 = fmaf(d, row[x], a0);
-                a1 = fmaf(d, row[x + 1], a1);
-                a2 = fmaf(d, row[x + 2], a2);
+            for (int ks = 0; ks < 16; ++ks) {
+                av[ks] = dc[4 * ks];                                        // A[c = li][pos = 4 ks + g]
+                const float p = ob[(ks >> 1) * 10 + 4 * (ks & 1)];          // B[pos][k]: obs[ci][y + dy][x + dx], y = pos >> 3, x = pos & 7
+                bv[ks] = k < K ? p : kone;
             }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) acc = mfma16(av[ks], bv[ks], acc);
         }
-        s_par[item * 3 + 0] = a0;
-        s_par[item * 3 + 1] = a1;
-        s_par[item * 3 + 2] = a2;
+    }
+    __syncthreads();                                                        // (the images are dead: the scratch aliases them)
+    if (grp < G) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(grp * NT + nt) * 256 + r * 64 + lane] = acc[r];
     }
     __syncthreads();
     PRISM_STAMP(23);
-    const int nk = 9 * C;
     float *out = a.ws.convpart + (int64_t)cb * CONV_ROW;
-    for (int o = tid; o < 16 * nk; o += 1024) {   // o = c*9C + ci*9 + dy*3 + dx  ==  (c*3C + ci*3 + dy)*3 + dx
+    for (int i = tid; i < NT * 256; i += 1024) {                            // (six k tiles at ten channels: two trips)
+        const int tn = i >> 8, e = i & 255, r = e >> 6, ln = e & 63;
+        const int c = 4 * (ln >> 4) + r, k = 16 * tn + (ln & 15);
         float t = 0.f;
-        for (int s = 0; s < ns; ++s) t += s_par[s * per_s * 3 + o];
-        out[o] = t;
-    }
-    if (tid < 16) {
-        float acc = 0.f;
-        for (int s = 0; s < ns; ++s)
-            for (int i = 0; i < 64; ++i) acc += s_dc[s * (16 * 65) + tid * 65 + i];
-        out[16 * nk + tid] = acc;
+        for (int q = 0; q < G; ++q) t += lds[(q * NT + tn) * 256 + e];
+        if (k < K) out[c * K + k] = t;
+        else if (k == K) out[16 * K + c] = t;
     }
 }
 

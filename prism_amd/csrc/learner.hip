@@ -17,6 +17,7 @@
 #include "act_kernels.h"
 #include "qbwd2_kernels.h"
 #include "bwd3_kernels.h"
+#include "bwd4_kernels.h"
 
 namespace prism {
 
@@ -95,7 +96,7 @@ static bool width_ok(int h) { return h == 128 || h == 256; }
 
 // Forward GEMMs: 1 = exact fp32 chain (v_mfma_f32_16x16x4_f32), 2 = three-piece bf16 operands on v_mfma_f32_16x16x32_bf16
 // (fp32 accuracy, common.h).  prism_learner_desc.gemm_mode picks one, 0 = the library default (PRISM_GEMM=fp32|bf16x3
-// overrides it); widths other than 128 always take the fp32 chain.
+// overrides it).
 static int default_gemm_mode() {
     static const int mode = [] {
         const char *e = getenv("PRISM_GEMM");
@@ -109,8 +110,6 @@ static int use_split(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     const int mode = ld->gemm_mode == PRISM_GEMM_FP32 || ld->gemm_mode == PRISM_GEMM_BF16X3 ? ld->gemm_mode : default_gemm_mode();
     if (mode != PRISM_GEMM_BF16X3) return 0;
-    if (d.use_iqn && d.iqn_width != 128) return 0;
-    if (d.n_heads && d.head_layers == 2 && d.head_width != 128) return 0;
     return (d.use_iqn || (d.n_heads && d.head_layers == 2)) ? 1 : 0;
 }
 
@@ -121,6 +120,12 @@ static bool use_bw3(const prism_learner_desc *ld) {
     return !off && d.use_iqn && use_split(ld) && bw3_ok(d.iqn_width, ld->batch, d.n_tau, true);
 }
 
+// ... and its width-256 form (bwd4_kernels.h: pairs of waves share 16 columns, one hidden half each)
+static bool use_bw4(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    static const bool off = [] { const char *e = getenv("PRISM_NO_BWD4"); return e && atoi(e) != 0; }();
+    return !off && d.use_iqn && use_split(ld) && bw4_ok(d.iqn_width, ld->batch, d.n_tau);
+}
 static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
@@ -190,7 +195,7 @@ static size_t carve_iqn(const prism_model_dims *d, int B, void *base, IqnWs *ws,
     w.de_iqn = c.f((size_t)B * E_DIM);
     w.slabs = c.f((size_t)MAX_CHUNKS * iqn_slab_floats((int)Hi, ln));
     {
-        const size_t post_rows = (size_t)((B + CONV_SPB - 1) / CONV_SPB) * CONV_ROW;
+        const size_t post_rows = (size_t)((B + 3) / 4) * CONV_ROW;      // (post_conv_blocks(B, C) <= this)
         const size_t bwd_rows = (size_t)(E_DIM / 16) * MAX_CHUNKS * BWD_CONV_ROW;
         const size_t dqn_rows = d->head_layers == 1 && d->n_heads ? (size_t)B * CONV_ROW : 0;   // one row per sample
         const size_t m = post_rows > bwd_rows ? post_rows : bwd_rows;
@@ -284,9 +289,17 @@ static int check_learner(const prism_learner_desc *ld, bool need_batch = true) {
 // beside clip + Adam (back launch, 256-thread workgroups: one leaf per thread)
 static bool split_writeback(const prism_learner_desc *ld) { return ld->batch <= 256; }
 
+static int bwd_row_chunks(const prism_learner_desc *ld) {
+    const prism_model_dims &d = ld->dims;
+    if (use_bw3(ld)) return BW3_RC;
+    if (use_bw4(ld)) return bw4_chunks(ld->batch, d.n_tau);
+    return bwd_chunks(iqn_width(d));
+}
+
 static bool conv_in_bwd(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     if (use_bw3(ld)) return bw3_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch);
+    if (use_bw4(ld)) return false;
     return bwd_conv_ok(d.use_iqn, d.n_heads, d.propagate_grad, d.n_tau, d.in_channels, ld->batch, bwd_chunks(iqn_width(d)),
                        iqn_width(d));
 }
@@ -294,9 +307,9 @@ static bool conv_in_bwd(const prism_learner_desc *ld) {
 static int post_block_count(const prism_learner_desc *ld) {
     const prism_model_dims &d = ld->dims;
     if (d.head_layers == 1 && d.n_heads) return post_blocks_dqn1(d.in_channels);
-    return post_blocks(ld->batch, d.use_iqn, d.n_heads, conv_in_bwd(ld), iqn_slab_floats(iqn_width(d), d.use_layer_norm),
+    return post_blocks(ld->batch, d.in_channels, d.use_iqn, d.n_heads, conv_in_bwd(ld), iqn_slab_floats(iqn_width(d), d.use_layer_norm),
                        q_slab_floats(head_width(d), d.use_layer_norm), iqn_width(d), head_width(d),
-                       use_bw3(ld) ? BW3_RC : bwd_chunks(iqn_width(d)));
+                       bwd_row_chunks(ld));
 }
 
 static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
@@ -316,7 +329,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.ln = d.use_layer_norm;
     a.slab = iqn_slab_floats(a.Hi, a.ln);
     a.q_slab = q_slab_floats(a.Hq, a.ln);
-    a.n_chunks = use_bw3(ld) ? BW3_RC : bwd_chunks(a.Hi);
+    a.n_chunks = bwd_row_chunks(ld);
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
@@ -626,12 +639,12 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
                             hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true, 4>), dim3(tiles), dim3(256), lds4, stream, aa);
                         return;
                     }
-                    if (aa.split) {
-                        herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
-                        if (herr == hipSuccess)
-                            hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
-                        return;
-                    }
+                }
+                if (aa.split) {
+                    herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
+                    if (herr == hipSuccess)
+                        hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
+                    return;
                 }
                 herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
                 if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
@@ -701,6 +714,21 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
         }
         if (herr != hipSuccess) {
             set_error("hipFuncSetAttribute(iqn_bwd3): %s", hipGetErrorString(herr));
+            return PRISM_ERR_HIP;
+        }
+        PRISM_CHECK_LAUNCH();
+    } else if (ld->dims.use_iqn && use_bw4(ld)) {
+        ProfileScope ps_(K_BWD, stream);
+        const dim3 grid((E_DIM / 32) * a.n_chunks);
+        if (a.ln) {
+            herr = set_max_lds((const void *)iqn_bwd4_kernel<true>, BW4_LDS_BYTES);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd4_kernel<true>), grid, dim3(512), BW4_LDS_BYTES, stream, a);
+        } else {
+            herr = set_max_lds((const void *)iqn_bwd4_kernel<false>, BW4_LDS_BYTES);
+            if (herr == hipSuccess) hipLaunchKernelGGL((iqn_bwd4_kernel<false>), grid, dim3(512), BW4_LDS_BYTES, stream, a);
+        }
+        if (herr != hipSuccess) {
+            set_error("hipFuncSetAttribute(iqn_bwd4): %s", hipGetErrorString(herr));
             return PRISM_ERR_HIP;
         }
         PRISM_CHECK_LAUNCH();
@@ -866,12 +894,12 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
                         hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true, 4>), dim3(tiles), dim3(256), lds4, stream, aa);
                     return;
                 }
-                if (aa.split) {
-                    herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
-                    if (herr == hipSuccess)
-                        hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
-                    return;
-                }
+            }
+            if (aa.split) {
+                herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL, true>, lds);
+                if (herr == hipSuccess)
+                    hipLaunchKernelGGL((fwd_tile_kernel<HH, LL, true>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);
+                return;
             }
             herr = set_max_lds((const void *)fwd_tile_kernel<HH, LL>, lds);
             if (herr == hipSuccess) hipLaunchKernelGGL((fwd_tile_kernel<HH, LL>), dim3(tiles), dim3(fw_threads(HH)), lds, stream, aa);

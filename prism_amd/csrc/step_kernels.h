@@ -444,9 +444,10 @@ __host__ __device__ inline int post_q_slab_blocks(int n_heads, int q_slab) {
     const int full = (n_heads * (q_slab / 4) + 1023) / 1024;
     return full < POST_Q_SLAB_MAX ? full : POST_Q_SLAB_MAX;
 }
-__host__ __device__ inline int post_blocks(int B, int use_iqn, int n_heads, bool conv_in_bwd, int slab, int q_slab, int Hi,
+__host__ __device__ inline int post_conv_blocks(int B, int C) { return (B + conv_spb(C) - 1) / conv_spb(C); }
+__host__ __device__ inline int post_blocks(int B, int C, int use_iqn, int n_heads, bool conv_in_bwd, int slab, int q_slab, int Hi,
                                            int Hq, int n_chunks = 8) {
-    int n = conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB;
+    int n = conv_in_bwd ? 1 : post_conv_blocks(B, C);
     if (use_iqn) n += post_slab_blocks(slab, n_chunks) + post_small_blocks(Hi);
     if (n_heads) n += post_q_slab_blocks(n_heads, q_slab) + n_heads * post_small_blocks(Hq);
     return n;
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     __shared__ float s_parts[Q_MAX_HEADS * Q_NORM_PARTS], s_norm2[Q_MAX_HEADS];
     const int tid = threadIdx.x, B = a.B, C = a.C;
     const bool dqn1 = a.head_layers == 1 && a.n_heads;
-    const int n_conv = dqn1 ? dqn1_conv_blocks(C) : (a.conv_in_bwd ? 1 : (B + CONV_SPB - 1) / CONV_SPB);
+    const int n_conv = dqn1 ? dqn1_conv_blocks(C) : (a.conv_in_bwd ? 1 : post_conv_blocks(B, C));
     int blk = bid;
     float sq = 0.f;
     float4 g_own = make_float4(0.f, 0.f, 0.f, 0.f);     // (fused tail) the slab sum of this thread, kept for its Adam update

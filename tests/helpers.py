@@ -84,6 +84,21 @@ def build_init_state(cfg, seed, C=4, A=6):
     return sd, tgt
 
 
+def jitter_grads(sd, tgt, spec, batch, w, taus, seed, draws=6, ulps=2.4e-7):
+    """The oracle's fp32 gradient at parameters jittered by about two units in the last place (`draws` times): where
+    these disagree with the plain fp32 gradient, a ReLU unit sits within rounding distance of zero and two correct
+    evaluations may differ by its whole contribution."""
+    from oracle.learner_ref import LearnerOracle
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(draws):
+        jit = {k: v * (1.0 + ulps * torch.randn(v.shape, generator=gen)) for k, v in sd.items()}
+        pj = LearnerOracle(jit, spec, tgt)
+        pj.update(batch, w, taus, apply=False)
+        out.append(pj.last["grads"])
+    return out
+
+
 def checksums(sd):
     s = np.array([float(v.double().sum()) for v in sd.values()])
     l2 = np.array([float(v.double().norm()) for v in sd.values()])

@@ -25,22 +25,42 @@ def dev():
     return "cuda:0"
 
 
-def updated_agent(name, dev, **extra):
+def updated_agent(name, dev, with_oracle=False, **extra):
     g = H.load_case(name)
     cfg, agent = build_hip_agent(g, dev, **extra)
+    orc = None
+    if with_oracle:
+        from oracle.learner_ref import LearnerOracle
+        cpu_cfg = H.case_config(g)
+        sd, tgt = H.build_init_state(cpu_cfg, int(g["seed"]), C=int(g["C"]), A=int(g["A"]))
+        orc = LearnerOracle(sd, H.spec_from_config(cpu_cfg, C=int(g["C"]), A=int(g["A"])), tgt)
     for step in range(int(g["steps"])):
         batch, w, taus = H.case_batch(g, step)
         agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev), taus=[t.to(dev) for t in taus])
+        if orc is not None:
+            orc.update(batch, w, taus)
         if cfg.use_target_network and step == 0:
             agent.sync_target_model()
-    return g, cfg, agent
+            if orc is not None:
+                orc.sync_target()
+    return (g, cfg, agent, orc) if with_oracle else (g, cfg, agent)
 
 
 @pytest.mark.parametrize("gemm_mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", IQN_CASES)
 def test_acting_matches_reference(dev, name, gemm_mode):
-    g, cfg, agent = updated_agent(name, dev, gemm_mode=gemm_mode)
+    g, cfg, agent, orc = updated_agent(name, dev, with_oracle=True, gemm_mode=gemm_mode)
     obs, taus, ref = H.case_act(g)
+    # (1) on the parameters the device's own updates left: the packed weight copies follow the update (stale ones would be
+    # off by the size of two Adam steps, ~1e-2).  Not held to 1e-5: where an update met a ReLU unit within rounding distance
+    # of zero (tests/test_gpu_learner.py: abl_ln_notarget, step 1) two correct updates differ by up to lr per element.
+    q, dist = agent.act_estimates(obs.to(dev), taus=None if taus is None else taus.to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(q.cpu().numpy(), ref["q"], rtol=0, atol=2e-4)
+    # (2) the acting forward itself, on the oracle's parameters after the same updates (pinned to the reference's:
+    # tests/test_oracle_golden.py), at the parity tolerance
+    agent.model.load_state_dict(orc.state_dict())
+    agent._params_replaced()
     q, dist = agent.act_estimates(obs.to(dev), taus=None if taus is None else taus.to(dev))
     torch.cuda.synchronize()
     assert tuple(q.shape) == ref["q"].shape

@@ -6,7 +6,18 @@ import numpy as np, torch
 from prism_amd.config import baseline_config
 from prism_amd.learner import Learner
 from prism_amd.synthetic import fill_replay
-cfg = baseline_config(int(sys.argv[1]) if len(sys.argv) > 1 else 2, device="cuda:0")
+_arg = sys.argv[1] if len(sys.argv) > 1 else "2"
+if _arg in ("add", "add_per", "add_ids", "sub"):
+    # the reference's ablation presets (tools/bench_presets.py): width 256, T = 32, batch 64
+    from prism_amd import config as C
+    _base, _over = {"add": (C.ADDITIVE_ABLATION_BASE_CONFIG, {}),
+                    "add_per": (C.ADDITIVE_ABLATION_BASE_CONFIG, dict(use_per=True, n_step_returns_length=3, use_layer_norm=True)),
+                    "add_ids": (C.ADDITIVE_ABLATION_BASE_CONFIG, dict(use_ids=True, ids_n_q_head_model_layers=2, ids_n_q_heads=10,
+                                                                      ids_q_head_feature_dim=256, ids_ensemble_variation_coef=0)),
+                    "sub": (C.SUBTRACTIVE_ABLATION_BASE_CONFIG, {})}[_arg]
+    cfg = C.derive(_base, device="cuda:0", experience_replay_capacity=100_000, log_to_wandb=False, **_over)
+else:
+    cfg = baseline_config(int(_arg), device="cuda:0")
 cfg.hip_graph = False
 ln = Learner()
 with contextlib.redirect_stdout(io.StringIO()):
