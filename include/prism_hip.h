@@ -246,7 +246,7 @@ typedef struct prism_learner_desc {
      * fp32 MFMA chain; PRISM_GEMM_BF16X3 = every fp32 operand as the sum of three bf16 pieces, the six leading piece
      * products on the bf16 matrix pipe with fp32 accumulation (what is dropped is of the size of one fp32 rounding; same rms
      * error against float64 as the fp32 chain, profiles/r03_split_bf16_ubench.txt); 0 = library default (environment
-     * PRISM_GEMM=fp32|bf16x3 overrides the default).  Hidden widths other than 128 always take the fp32 chain. */
+     * PRISM_GEMM=fp32|bf16x3 overrides the default).  Both forms cover hidden widths 128 and 256. */
     int32_t gemm_mode;
     /* outputs */
     float *out_dist_loss;     /* [B] or NULL  (Agent._static_distribution_loss)               */

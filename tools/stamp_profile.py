@@ -139,6 +139,23 @@ sl = s[n_conv:n_conv + n_slab].astype(np.float64)
 if sl[:, 7].any():
     print("   slab phases (kernel entry -> role code reached | 8 chunk loads arrived | store + norm partial written):",
           [int(np.median(x)) for x in (sl[:, 8] - sl[:, 13], sl[:, 7] - sl[:, 8], sl[:, 14] - sl[:, 7])])
+# explicit role layout (STAMP_ROLES="conv:64,slab:49,small:8,qslab:32,qsmall:80,wb:1"): per role, when its blocks start, finish
+# their role (slot 14) and -- fused tail -- get past the barrier (25) and end (9), ticks after the launch's first stamp
+if os.environ.get("STAMP_ROLES"):
+    # (the chip-wide 100 MHz real-time counter, slots 32 + k: the shader clocks of different XCDs do not compare)
+    lo_ = 0
+    allrows = np.arange(0, sum(int(p_.split(":")[1]) for p_ in os.environ["STAMP_ROLES"].split(",")))
+    t0r = s[allrows, 32 + 13].astype(np.float64).min()
+    print("   role            n   start med/max us   role end med/max us   past barrier med/max us   end med/max us")
+    for part in os.environ["STAMP_ROLES"].split(","):
+        nm, cnt = part.split(":"); cnt = int(cnt)
+        rows = np.arange(lo_, lo_ + cnt); lo_ += cnt
+        g_ = lambda k: (s[rows, 32 + k].astype(np.float64) - t0r) / 100.0
+        f_ = lambda x: f"{np.median(x):7.2f}/{np.max(x):7.2f}"
+        print(f"   {nm:10s} {cnt:4d}   {f_(g_(13))}   {f_(g_(14))}   {f_(g_(25)) if (s[rows, 32 + 25] != 0).any() else '-':>15s}   {f_(g_(9)) if (s[rows, 32 + 9] != 0).any() else '-':>15s}")
+        late = rows[np.argsort(-g_(14))[:3]]
+        print("        latest three (block: start, stamps 22 / 23 / 20 / 21, role end):",
+              "; ".join(f"{int(r_)}: " + " ".join(f"{(float(s[r_, 32 + k]) - t0r) / 100.0:6.2f}" if s[r_, 32 + k] else "     -" for k in (13, 22, 23, 20, 21, 14)) for r_ in late))
 # fused tail (slots 25 = past the grid barrier, 9 = Adam done), role blocks only
 tb = pb & (s[:, 25] != 0)
 if tb.any():
