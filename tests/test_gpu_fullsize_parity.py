@@ -183,6 +183,13 @@ CASES = {
     # the exact fp32 MFMA chain in the forward GEMMs (the default is the three-piece bf16 form, prism_hip.h gemm_mode)
     "c3_iqn_per_fp32": dict(base=2, B=256, cap=100_000, gemm_mode="fp32"),
     "c4_full_fp32": dict(base=3, B=512, cap=100_000, target_update_period=40, gemm_mode="fp32"),
+    # the ablation presets' shape (width 256, T = 32, batch 64) through the fused graph step with PER + 3-step returns: the bf16
+    # forward tiles at H = 256 and iqn_bwd4_kernel, 100 steps against the oracle; and the full model at that width
+    "w256_t32_iqn_per": dict(base=2, B=64, cap=100_000, iqn_quantile_model_feature_dim=256,
+                             iqn_n_current_state_quantile_samples=32, iqn_n_next_state_quantile_samples=32),
+    "w256_t32_full": dict(base=3, B=64, cap=100_000, target_update_period=40, iqn_quantile_model_feature_dim=256,
+                          ids_q_head_feature_dim=256, iqn_n_current_state_quantile_samples=32,
+                          iqn_n_next_state_quantile_samples=32),
 }
 
 

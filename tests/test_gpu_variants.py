@@ -26,6 +26,18 @@ CASES = {
     "tau16_target": dict(B=16, C=4, over=dict(iqn_n_current_state_quantile_samples=16,
                                               iqn_n_next_state_quantile_samples=16, use_target_network=True,
                                               use_double_q_learning=True)),
+    # hidden width 256 (the ablation presets' width) away from their T = 32, B = 64: the bf16 forward tiles at H = 256 with
+    # the loss inside the tile (T <= 8) or behind it, and every row-chunk count / sample-sum path of iqn_bwd4_kernel
+    # (bwd4_kernels.h bw4_chunks: 8, 4; T = 4, 8, 16, 64)
+    "w256_tau8": dict(B=64, C=4, over=dict(iqn_quantile_model_feature_dim=256)),
+    "w256_tau4": dict(B=32, C=4, over=dict(iqn_quantile_model_feature_dim=256, iqn_n_current_state_quantile_samples=4,
+                                           iqn_n_next_state_quantile_samples=4)),
+    "w256_tau16_c7": dict(B=32, C=7, over=dict(iqn_quantile_model_feature_dim=256, iqn_n_current_state_quantile_samples=16,
+                                               iqn_n_next_state_quantile_samples=16)),
+    "w256_tau64_target": dict(B=16, C=4, over=dict(iqn_quantile_model_feature_dim=256, iqn_n_current_state_quantile_samples=64,
+                                                   iqn_n_next_state_quantile_samples=64, use_target_network=True,
+                                                   use_double_q_learning=True)),
+    "w256_noln_ragged48": dict(B=48, C=4, over=dict(iqn_quantile_model_feature_dim=256, use_layer_norm=False)),
 }
 
 
@@ -73,24 +85,37 @@ def test_variant_matches_oracle(name):
     # (seed chosen so that no trunk pre-activation sits within rounding distance of the ReLU kink:
     # there the HIP and the autograd gradients legitimately differ by a whole unit's contribution)
     rng = np.random.default_rng(1)
+    wide = cfg.iqn_quantile_model_feature_dim >= 256
     for step in range(3):
         batch, w, taus = _batch(rng, B, C, A, cfg)
+        pre_sd = orc.state_dict()
+        pre_tgt = None if orc.p_tgt is None else {k: v.clone() for k, v in orc.p_tgt.items()}
         td_o = orc.update(batch, w, taus)
         td = agent.update(to_hip_batch(batch, dev), per_weights=w.to(dev), taus=[t.to(dev) for t in taus])
         torch.cuda.synchronize()
         np.testing.assert_allclose(td.cpu().numpy(), td_o.numpy(), rtol=0, atol=1e-5)
         assert abs(float(agent._static_total_loss) - float(orc.last["total"])) < 1e-5
         off, gflat = 0, agent.grads.cpu()
+        jitter, allowance = None, {}
         for k in sd:
             n = sd[k].numel()
             go = orc.last["grads"][k].reshape(-1)
             tol = 1e-4 * float(go.abs().max()) + 1e-7
             err = float((gflat[off:off + n] - go).abs().max())
-            assert err <= tol, f"{name} step {step} grad {k}: max err {err:.3e} > {tol:.3e}"
+            kink = 0.0
+            if err > tol and wide:
+                # width 256: a ReLU unit within rounding distance of zero -- bounded by what the oracle shows on itself
+                # under a two-ulp parameter jitter (tests/test_gpu_learner.py)
+                if jitter is None:
+                    jitter = H.jitter_grads(pre_sd, pre_tgt, H.spec_from_config(cpu_cfg, C=C, A=A), batch, w, taus, seed=77 + step)
+                kink = 2.0 * max(float((jg[k].reshape(-1) - go).abs().max()) for jg in jitter)
+            allowance[k] = kink
+            assert err <= tol + kink, f"{name} step {step} grad {k}: max err {err:.3e} > {tol:.3e} + {kink:.3e}"
             off += n
         post = agent.model.state_dict()
         for k, v in orc.state_dict().items():
-            np.testing.assert_allclose(post[k].cpu().numpy(), v.numpy(), rtol=0, atol=2e-6, err_msg=k)
+            np.testing.assert_allclose(post[k].cpu().numpy(), v.numpy(), rtol=0,
+                                       atol=2e-6 + cfg.learning_rate * allowance[k] / cfg.adam_epsilon, err_msg=k)
         if cfg.use_target_network and step == 0:
             agent.sync_target_model()
             orc.sync_target()
