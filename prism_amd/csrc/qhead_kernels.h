@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     float *dpl = smem + w * QB_STAGE;
     float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area after the barrier
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
+    PRISM_STAMP(27);
     float w1f[4 * NHT];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n]
     {
         const float *src = Ph + a.off.h_w1 + n;
@@ -361,7 +362,9 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
         }
     }
     // fold the four waves in fixed order and write this head's slab slice
+    PRISM_STAMP(28);
     __syncthreads();
+    PRISM_STAMP(29);
     {
         float *mine = red + (w * QB_ACC) * 64 + lane;
 #pragma unroll
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
             else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
         }
     }
+    PRISM_STAMP(30);
 }
 
 // ---- post-kernel roles ---------------------------------------------------------------------------

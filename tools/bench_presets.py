@@ -24,13 +24,14 @@ for name, (base, over) in CASES.items():
         ln.configure(cfg, obs_shape=(10, 10, 4), n_actions=6)
     ln.time_phases = False
     fill_replay(ln.experience_buffer, ln.experience_buffer.capacity, seed=0)
-    for _ in range(100):
-        ln.step()
+    n = int(os.environ.get("PRESET_STEPS", "1000"))            # (counter passes: PRESET_STEPS=40 PRESET_EAGER=1)
+    eager = os.environ.get("PRESET_EAGER") == "1"
+    for _ in range(min(100, n)):
+        ln.step(eager=eager)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 1000
     for _ in range(n):
-        ln.step()
+        ln.step(eager=eager)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{name:72s} {n / dt:9.0f} steps/s  {dt / n * 1e6:7.1f} us/step  params {ln.agent.flat.numel()}")

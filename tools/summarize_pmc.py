@@ -11,7 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, n = sys.argv[1], int(sys.argv[2])
-cfg = "configs" + (sys.argv[3] if len(sys.argv) > 3 else "2")
+_c = sys.argv[3] if len(sys.argv) > 3 else "2"
+cfg = "configs" + _c if _c.isdigit() else _c          # BASELINE.json configs[i], or a label such as preset_additive
 kern = collections.defaultdict(dict)
 for k in range(n):
     f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}_{k}", "*", "*counter_collection.csv")))[0]
