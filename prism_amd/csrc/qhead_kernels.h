@@ -280,21 +280,27 @@ __host__ __device__ constexpr int qb_acc(int H) { return H / 4 + 2; }           
 __host__ __device__ constexpr int qb_stage(int H) { return qb_acc(H) * 64; }       // per-wave staging floats: dpre1 tile (16*(H+4)) aliased with the fold buffer
 __host__ __device__ constexpr int qb_lds_floats(int H) { return 4 * qb_stage(H); }
 
-template <int H, bool LN>
+// COLS (small batches: B <= 128): a workgroup takes (head, FOUR column slices), each wave ONE slice over ALL sample tiles, so a
+// wave owns its columns outright -- no fold across waves, no barrier, a quarter of the workgroups.  At B = 64 the row-split form
+// gives every wave ONE tile: 640 workgroups of 22.9 k cycles each (16.8 k of them the wave's 80 operand loads and their round
+// trip for 4 k cycles of matrix work), one resident per CU (its registers), i.e. three rounds: 30.5 us for 0.7 GFLOP (stamps,
+// subtractive ablation preset); this form: 25.2 us (22.6 without LayerNorm).  Requesting the next tile's rows before the
+// current tile's products (software pipeline through the wave's LDS image) measured no better (27.0 / 22.2 us): not kept.
+template <int H, bool LN, bool COLS = false>
 __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     constexpr int NHT = H / 16, HS = H + 4, QB_ACC = qb_acc(H), QB_STAGE = qb_stage(H);
     static_assert(16 * HS <= QB_STAGE, "dpre1 tile must fit the per-wave staging area");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-    const int cs = blockIdx.x % (E_DIM / 16), hd = blockIdx.x / (E_DIM / 16);
+    const int cs = COLS ? 4 * (blockIdx.x % (E_DIM / 64)) + w : blockIdx.x % (E_DIM / 16);
+    const int hd = COLS ? blockIdx.x / (E_DIM / 64) : blockIdx.x / (E_DIM / 16);
     const int n = cs * 16 + j;
     const int B = a.B;
     const int tiles_total = B / 16;
     float *dpl = smem + w * QB_STAGE;
     float *red = smem;                            // [4 waves][QB_ACC][64], reuses the staging area after the barrier
     const float *Ph = a.params + a.off.head_base + (int64_t)hd * a.off.head_stride;
-    PRISM_STAMP(27);
     float w1f[4 * NHT];    // B operand of dX: W1_h[hh = 16q + 4g + jj][n]
     {
         const float *src = Ph + a.off.h_w1 + n;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
     for (int i = 0; i < NHT; ++i) accW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     float s_dg = 0.f, s_db = 0.f;
     float *de_h = a.ws.de_q + (size_t)hd * B * E_DIM;
-    for (int t = w; t < tiles_total; t += 4) {
+    for (int t = COLS ? 0 : w; t < tiles_total; t += COLS ? 1 : 4) {
         const int b0 = t * 16;
         const int64_t row0 = (int64_t)hd * B + b0;
         float4 ad[NHT];
@@ -361,10 +367,26 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
                 accW1[mt] = mfma16(dpl[(4 * g + r) * HS + 16 * mt + j], xv[r], accW1[mt]);
         }
     }
+    float *slab = a.ws.q_slabs + (int64_t)hd * a.q_slab;
+    constexpr int W1_OFF = LN ? 2 * E_DIM : 0;
+    if constexpr (COLS) {
+        // the wave's columns over all rows: straight to the slab
+#pragma unroll
+        for (int mt = 0; mt < NHT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[W1_OFF + (int64_t)(16 * mt + 4 * g + r) * E_DIM + n] = accW1[mt][r];
+        s_dg += __shfl_xor(s_dg, 16, 64);
+        s_dg += __shfl_xor(s_dg, 32, 64);
+        s_db += __shfl_xor(s_db, 16, 64);
+        s_db += __shfl_xor(s_db, 32, 64);
+        if (LN && g == 0) {
+            slab[n] = s_dg;
+            slab[E_DIM + n] = s_db;
+        }
+        return;
+    }
     // fold the four waves in fixed order and write this head's slab slice
-    PRISM_STAMP(28);
     __syncthreads();
-    PRISM_STAMP(29);
     {
         float *mine = red + (w * QB_ACC) * 64 + lane;
 #pragma unroll
@@ -379,8 +401,6 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
         mine[(4 * NHT + 1) * 64] = s_db;
     }
     __syncthreads();
-    float *slab = a.ws.q_slabs + (int64_t)hd * a.q_slab;
-    constexpr int W1_OFF = LN ? 2 * E_DIM : 0;
     for (int idx = tid; idx < QB_ACC * 64; idx += 256) {
         const int slot = idx >> 6, l = idx & 63;
         const float v = ((red[(0 * QB_ACC + slot) * 64 + l] + red[(1 * QB_ACC + slot) * 64 + l]) +
@@ -394,7 +414,6 @@ __global__ __launch_bounds__(256) void qh_bwd_kernel(IqnArgs a) {
             else slab[E_DIM + cs * 16 + lj] = v;               // d ln1_b
         }
     }
-    PRISM_STAMP(30);
 }
 
 // ---- post-kernel roles ---------------------------------------------------------------------------
