@@ -144,6 +144,11 @@ int prism_per_query(const prism_replay_desc *rp, int64_t size, float *out2, pris
  * (prism/agents/models/composite_model.py:94-144, iqn_model.py:48-201, q_ensemble.py:44-92,
  *  prism/agents/agent.py:53-79), fp32 throughout.
  * ------------------------------------------------------------------------------------------ */
+/* prism_model_dims.squish_fn (/root/reference/prism/agents/squish_functions.py:4-18) */
+#define PRISM_SQUISH_NONE 0
+#define PRISM_SQUISH_OBS_LOOK_FURTHER 1   /* sign(x) (sqrt(|x| + 1) - 1) + 0.01 x  and its inverse   */
+#define PRISM_SQUISH_SYMLOG 2             /* sign(x) log(|x| + 1)  /  sign(x) (exp(|x|) - 1)          */
+
 typedef struct prism_model_dims {
     int32_t in_channels;   /* C; observations are (10,10,C) NHWC                              */
     int32_t n_actions;     /* A <= 16                                                         */
@@ -165,6 +170,8 @@ typedef struct prism_model_dims {
     float dist_loss_weight;
     float q_loss_weight;
     float theil_coef;      /* ids_ensemble_variation_coef                                     */
+    int32_t squish_fn;     /* PRISM_SQUISH_*: loss_squish_fn_id (model_factory.py:16-23): the TD target is
+                            * squish(r + gamma' * unsquish(z_next)) (iqn_model.py:141-148, q_ensemble.py:77-82) */
 } prism_model_dims;
 
 /* Offsets (in floats) of each tensor inside the flat parameter buffer, which is laid out in
@@ -329,10 +336,11 @@ int prism_act_forward(const prism_learner_desc *ld, const float *obs, int32_t n,
  * (prism/agents/action_selectors.py:125-176): scores [n][A] = regret^2 / information gain, action [n] = argmin.
  * z / q: the buffers prism_act_forward filled.  out_aux (optional) [n][4][A]: ensemble mean, ensemble spread
  * (torch.std), return-distribution variance, information gain -- what the selector logs.  out_action_host (optional): a
- * second destination of the actions -- pinned, device-mapped host memory, so that the caller needs no device-to-host copy. */
+ * second destination of the actions -- pinned, device-mapped host memory, so that the caller needs no device-to-host copy.
+ * unsquish_fn (PRISM_SQUISH_*): the selector's unsquish function, applied to both estimate arrays first (:128-130). */
 int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
-                     int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
-                     float *out_aux, int64_t *out_action, int64_t *out_action_host, prism_stream_t stream);
+                     int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, int32_t unsquish_fn,
+                     float *out_scores, float *out_aux, int64_t *out_action, int64_t *out_action_host, prism_stream_t stream);
 
 /* GreedyActionSelector.generate_action_probs + select_action (prism/agents/action_selectors.py:70-83; also the greedy
  * branch of EGreedyActionSelector, :24-45): action [n] = argmax_a mean(q_estimates[:, a, :]).  q != NULL: mean over the

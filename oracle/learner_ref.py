@@ -40,6 +40,7 @@ class ModelSpec:
     n_tau: int = 8                # current-state quantile samples
     n_tau_next: int = 8
     huber_k: float = 1.0
+    squish: str = "none"          # loss_squish_fn_id: "obs_look_further" | "symlog" | anything else = none (model_factory.py:16-23)
     dist_loss_weight: float = 1.0
     propagate_grad: bool = True
     n_heads: int = 0              # 0: no q model; 1: DQN; 10: IDS ensemble
@@ -52,6 +53,17 @@ class ModelSpec:
     beta1: float = 0.9
     beta2: float = 0.999
     adam_eps: float = 1.5e-4
+
+
+def squish_pair(spec):
+    """(squish, unsquish) of the TD target, restating /root/reference/prism/agents/squish_functions.py:4-18 (same torch
+    operations in the same order, so fp32 and fp64 evaluations round as the reference's do); (None, None) without one."""
+    if spec.squish == "symlog":
+        return (lambda x: torch.sign(x) * torch.log(x.abs() + 1)), (lambda x: torch.sign(x) * (torch.exp(x.abs()) - 1))
+    if spec.squish == "obs_look_further":
+        return (lambda x: torch.sign(x) * (torch.sqrt(x.abs() + 1) - 1) + 0.01 * x), \
+               (lambda y: torch.sign(y) * (torch.square((torch.sqrt(1 + 4 * 0.01 * (torch.abs(y) + 1 + 0.01)) - 1) / (2 * 0.01)) - 1))
+    return None, None
 
 
 def conv_embed(p, obs):
@@ -120,7 +132,12 @@ def iqn_loss(p, p_tgt, spec, e_cur, e_next, acts, returns, dg, taus):
             z_on = z_tg
         a_star = z_on.view(Tn, B, -1).mean(dim=0).argmax(dim=-1).view(-1, 1)
         zsel = torch.gather(z_tg, 1, torch.tile(a_star, [Tn, 1]))
+        squish, unsquish = squish_pair(spec)                         # iqn_model.py:141-148
+        if unsquish is not None:
+            zsel = unsquish(zsel)
         y = torch.tile(returns.view(-1, 1), [Tn, 1]) + zsel * torch.tile(dg.view(-1, 1), [Tn, 1])
+        if squish is not None:
+            y = squish(y)
         y = y.view(Tn, B, 1).transpose(1, 0)                         # (B, T', 1)
     q = torch.gather(z_cur, 1, torch.tile(acts.view(-1, 1), [T, 1])).view(T, B, 1).transpose(1, 0)
     delta = y[:, :, None] - q[:, None, :]                             # (B, T', T, 1)
@@ -165,7 +182,12 @@ def qens_loss(p, p_tgt, spec, e_cur, e_next, acts, returns, dg):
             q_tg = q_on = qens_forward(p_tgt, spec, e_next)
         best = q_on.argmax(dim=-2)                                    # (B, heads)
         nxt = q_tg[ar[:, None], best, torch.arange(spec.n_heads)[None, :]]
+        squish, unsquish = squish_pair(spec)                         # q_ensemble.py:77-82
+        if unsquish is not None:
+            nxt = unsquish(nxt)
         target = returns.view(-1, 1) + nxt * dg.view(-1, 1)
+        if squish is not None:
+            target = squish(target)
     ql = F.mse_loss(q_cur[ar, acts, :], target, reduction="none").mean(dim=-1)
     theil = torch.tensor(0.0)
     if spec.theil_coef != 0:
@@ -191,9 +213,11 @@ def act_forward(p, spec, obs, taus):
     return q, dist
 
 
-def ids_scores(dist, q, lmbda, epsilon, rho_lower_bound):
+def ids_scores(dist, q, lmbda, epsilon, rho_lower_bound, unsquish=None):
     """IDSActionSelector.generate_action_probs without random sampling (action_selectors.py:125-176):
-    dict of the logged intermediates + the chosen action."""
+    dict of the logged intermediates + the chosen action.  `unsquish`: the selector's unsquish function (:128-130)."""
+    if unsquish is not None:
+        dist, q = unsquish(dist), unsquish(q)
     mean, variance = q.mean(dim=-1), q.std(dim=-1)
     std = torch.sqrt(variance)
     regret = torch.max(mean + lmbda * std, dim=-1).values.view(-1, 1) - (mean - lmbda * std)

@@ -41,7 +41,8 @@ class ModelDims(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in (
         "in_channels", "n_actions", "embed_dim", "use_iqn", "n_basis", "iqn_layers", "iqn_width", "n_tau",
         "n_tau_next", "use_layer_norm", "n_heads", "head_layers", "head_width", "has_target", "double_q",
-        "propagate_grad")] + [(n, c_f32) for n in ("huber_k", "dist_loss_weight", "q_loss_weight", "theil_coef")]
+        "propagate_grad")] + [(n, c_f32) for n in ("huber_k", "dist_loss_weight", "q_loss_weight", "theil_coef")] + \
+        [("squish_fn", c_i32)]
 
 
 class ParamOffsets(ctypes.Structure):
@@ -105,7 +106,7 @@ SIGNATURES = {
                                          c_vp]),
     "prism_step_back": (ctypes.c_int, [_P(LearnerDesc), _P(ReplayDesc), c_vp, c_f32, c_f32, c_vp]),
     "prism_act_forward": (ctypes.c_int, [_P(LearnerDesc), c_vp, c_i32, c_i32, c_vp, c_u64, c_u64, c_vp, c_vp, c_vp]),
-    "prism_ids_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp,
+    "prism_ids_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_i32, c_vp, c_vp,
                                         c_vp, c_vp, c_vp]),
     "prism_greedy_select": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "prism_sync_target": (ctypes.c_int, [c_vp, c_vp, c_i64, c_vp]),

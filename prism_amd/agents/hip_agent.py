@@ -154,6 +154,8 @@ def model_dims(config, in_channels, n_actions):
     d.propagate_grad = int((config.ids_allow_distributional_gradients and config.use_ids) or not config.use_ids)
     d.huber_k, d.dist_loss_weight = config.iqn_huber_loss_kappa, config.distributional_loss_weight
     d.q_loss_weight = config.q_loss_weight
+    from prism_amd.agents.squish_functions import SQUISH_IDS
+    d.squish_fn = SQUISH_IDS.get(str(config.loss_squish_fn_id), 0)       # (unknown ids parse to no squish, model_factory.py:16-23)
     return d
 
 
@@ -595,9 +597,11 @@ class HipAgent:
         q_tiles = dm.n_heads > 0 and dm.head_layers == 2
         q_rows = dm.n_heads > 0 and dm.head_layers == 1
         if type(sel) is IDSActionSelector:
-            if sel.random_sample or sel.unsquish_function is not None or not (dm.use_iqn and (q_tiles or q_rows)):
+            from prism_amd.agents.squish_functions import unsquish_id
+            usq = unsquish_id(sel.unsquish_function)
+            if sel.random_sample or usq is None or not (dm.use_iqn and (q_tiles or q_rows)):
                 return None
-            skey = ("ids", float(sel.lmbda), float(sel.epsilon), float(sel.ids_rho_lower_bound))
+            skey = ("ids", float(sel.lmbda), float(sel.epsilon), float(sel.ids_rho_lower_bound), usq)
         elif type(sel) is GreedyActionSelector:
             skey = ("greedy",)
         else:
@@ -665,7 +669,7 @@ class HipAgent:
                 d.rng_counters, d.act_flags = keep
             if skey[0] == "ids":
                 N.check(L.prism_ids_select(N.ptr(st["z"]), N.ptr(st["qb"]), n, st["n_pad"], T, A, dm.n_heads, skey[1], skey[2],
-                                           skey[3], N.ptr(st["scores"]), None, N.ptr(st["act"][slot]), N.ptr(st["pin_out"][slot]),
+                                           skey[3], skey[4], N.ptr(st["scores"]), None, N.ptr(st["act"][slot]), N.ptr(st["pin_out"][slot]),
                                            N.current_stream_handle()), "prism_ids_select")
             else:
                 N.check(L.prism_greedy_select(N.ptr(st["z"]), N.ptr(st["qb"]), n, st["n_pad"], T, A, dm.n_heads,
@@ -703,12 +707,14 @@ class HipAgent:
         z, qb, n, n_pad, T = self._act_raw
         A = self.dims.n_actions
         action = torch.empty(n, dtype=torch.int64, device=self.device)
-        if (type(sel) is IDSActionSelector and not sel.random_sample and sel.unsquish_function is None
+        from prism_amd.agents.squish_functions import unsquish_id
+        usq = unsquish_id(sel.unsquish_function) if type(sel) is IDSActionSelector else None
+        if (type(sel) is IDSActionSelector and not sel.random_sample and usq is not None
                 and z is not None and qb is not None):
             scores = torch.empty((n, A), device=self.device)
             with torch.cuda.device(self.device):
                 N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, self.dims.n_heads, float(sel.lmbda),
-                                                 float(sel.epsilon), float(sel.ids_rho_lower_bound), N.ptr(scores), None,
+                                                 float(sel.epsilon), float(sel.ids_rho_lower_bound), usq, N.ptr(scores), None,
                                                  N.ptr(action), None, N.current_stream_handle()), "prism_ids_select")
             self._act_scores = scores
             return action

@@ -18,6 +18,7 @@ struct IdsArgs {
     int64_t *action;     // [n] argmin of the scores (first minimum)
     int64_t *action2;    // optional second copy of the actions (pinned host memory: the caller needs no device-to-host copy)
     int stage;           // the observation's T x A estimates fit the launch's dynamic LDS: staged there in one round of loads
+    int unsquish;        // PRISM_SQUISH_*: the selector's unsquish function, applied to every estimate as it is read
 };
 
 constexpr int ACT_THREADS = 256;
@@ -48,11 +49,11 @@ __global__ __launch_bounds__(ACT_THREADS) void ids_score_kernel(IdsArgs k) {
     float mean = 0.f, spread = 0.f;
     if (lane < A) {
         float s = 0.f;
-        for (int h = 0; h < Hd; ++h) s += k.q[((int64_t)h * k.n_pad + b) * A + lane];
+        for (int h = 0; h < Hd; ++h) s += unsquish_value(k.unsquish, k.q[((int64_t)h * k.n_pad + b) * A + lane]);
         mean = s / (float)Hd;
         float v = 0.f;
         for (int h = 0; h < Hd; ++h) {
-            const float d = k.q[((int64_t)h * k.n_pad + b) * A + lane] - mean;
+            const float d = unsquish_value(k.unsquish, k.q[((int64_t)h * k.n_pad + b) * A + lane]) - mean;
             v += d * d;
         }
         spread = sqrtf(v / (float)(Hd > 1 ? Hd - 1 : 1));          // q_estimates.std(dim=-1): called "variance" there
@@ -66,11 +67,11 @@ __global__ __launch_bounds__(ACT_THREADS) void ids_score_kernel(IdsArgs k) {
     float var_mine = 0.f;
     for (int a = 0; a < A; ++a) {
         float s = 0.f;
-        for (int t = lane; t < T; t += 64) s += zb[t * A + a];
+        for (int t = lane; t < T; t += 64) s += unsquish_value(k.unsquish, zb[t * A + a]);
         const float m = wave_sum(s) / (float)T;
         float v = 0.f;
         for (int t = lane; t < T; t += 64) {
-            const float d = zb[t * A + a] - m;
+            const float d = unsquish_value(k.unsquish, zb[t * A + a]) - m;
             v += d * d;
         }
         const float var = wave_sum(v) / (float)(T > 1 ? T - 1 : 1);

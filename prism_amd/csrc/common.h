@@ -238,6 +238,30 @@ __host__ __device__ inline double u64_to_unit_double(uint32_t hi, uint32_t lo) {
     return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
 }
 
+// value squish of the TD target and its inverse (/root/reference/prism/agents/squish_functions.py:4-18; id = PRISM_SQUISH_*),
+// operation by operation as the reference's torch expressions evaluate them in fp32; sign(0) = 0
+__device__ __forceinline__ float sign_of(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+__device__ __forceinline__ float squish_value(int id, float x) {
+    if (id == PRISM_SQUISH_SYMLOG) return sign_of(x) * logf(fabsf(x) + 1.0f);
+    if (id == PRISM_SQUISH_OBS_LOOK_FURTHER) return sign_of(x) * (sqrtf(fabsf(x) + 1.0f) - 1.0f) + 0.01f * x;
+    return x;
+}
+__device__ __forceinline__ float unsquish_value(int id, float y) {
+    if (id == PRISM_SQUISH_SYMLOG) return sign_of(y) * (expf(fabsf(y)) - 1.0f);
+    if (id == PRISM_SQUISH_OBS_LOOK_FURTHER) {
+        // torch: sqrt(1 + 4 * 0.01 * (|y| + 1 + 0.01)): the Python scalars fold first (4 * 0.01 in double, then to fp32)
+        const float root = sqrtf(1.0f + (float)(4 * 0.01) * (fabsf(y) + 1.0f + 0.01f));
+        const float q = (root - 1.0f) / (float)(2 * 0.01);
+        return sign_of(y) * (q * q - 1.0f);
+    }
+    return y;
+}
+// squish(r + dg * unsquish(z)): separate multiply and add, as the reference writes it
+__device__ __forceinline__ float td_target(int id, float r, float z, float dg) {
+    if (id == PRISM_SQUISH_NONE) return r + z * dg;
+    return squish_value(id, r + unsquish_value(id, z) * dg);
+}
+
 // priority exponent with the same special cases torch.pow uses for scalar exponents
 // (0.5 -> sqrt, -0.5 -> 1/sqrt), so the default alpha = beta = 0.5 is correctly rounded on both
 // host and device.

@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void fwd_tile_kernel(IqnArgs a_by_va
         }
         float *y = s_y + smp * T, *q = s_q + smp * T;
         if (lane < T) {
-            y[lane] = R + zt[(rb + T + lane) * FW_ZS + astar] * dg;      // separate mul and add (iqn_model.py:145)
+            y[lane] = td_target(a.squish, R, zt[(rb + T + lane) * FW_ZS + astar], dg);      // separate mul and add (iqn_model.py:141-148)
             q[lane] = zt[(rb + lane) * FW_ZS + act];
         }
         __builtin_amdgcn_wave_barrier();

@@ -119,6 +119,7 @@ struct IqnArgs {
     int q_de_slots;        // slots of ws.de_q that hold a share of the Q heads' embedding gradient (one per head, or the
                            // two K halves of qh_bwd2_kernel)
     int q_pieces;          // the Q loss also leaves dpre1 / xhat as bf16 pieces in ws.q_pp / ws.q_xp (experiments; 0)
+    int squish;            // PRISM_SQUISH_*: value squish of the TD target (common.h td_target)
     int split;             // forward GEMMs on the bf16 matrix pipe (three-piece operands, common.h); packed copies laid out for it
     int dbg;               // experiment switches (PRISM_DBG env), 0 in production
     unsigned long long *stamps;   // diagnostic builds only: [block][64] shader-clock stamps (dbg & 8)
@@ -497,7 +498,7 @@ __device__ __forceinline__ void iqn_loss_body(const IqnArgs &a, const int b) {
         PRISM_STAMP(21);
         const float R = a.reward[b];
         const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        if (lane < Tn) s_y[lane] = R + s_zt[lane * A + astar] * dg;     // separate mul and add (iqn_model.py:145)
+        if (lane < Tn) s_y[lane] = td_target(a.squish, R, s_zt[lane * A + astar], dg);     // separate mul and add (iqn_model.py:141-148)
         if (lane < T) s_q[lane] = s_zc[lane * A + act];
         __builtin_amdgcn_wave_barrier();
         // pairwise quantile-Huber tile: pair p = j*T + t; a lane keeps a fixed t because T | 64

@@ -130,6 +130,7 @@ static int iqn_supported(const prism_model_dims *d, int32_t B) {
     auto pow2_ok = [](int t) { return t == 4 || t == 8 || t == 16 || t == 32 || t == 64; };
     if (!d->use_iqn && d->n_heads == 0) return PRISM_ERR_UNSUPPORTED;
     if (d->embed_dim != E_DIM) return PRISM_ERR_UNSUPPORTED;
+    if (d->squish_fn < PRISM_SQUISH_NONE || d->squish_fn > PRISM_SQUISH_SYMLOG) return PRISM_ERR_UNSUPPORTED;
     if (d->use_iqn) {
         if (d->n_basis != K_BASIS || d->iqn_layers != 1 || !width_ok(d->iqn_width)) return PRISM_ERR_UNSUPPORTED;
         if (!pow2_ok(d->n_tau) || !pow2_ok(d->n_tau_next)) return PRISM_ERR_UNSUPPORTED;
@@ -333,6 +334,7 @@ static void fill_iqn_args(const prism_learner_desc *ld, IqnArgs &a) {
     a.has_target = d.has_target;
     a.double_q = d.double_q;
     a.propagate_grad = d.propagate_grad;
+    a.squish = d.squish_fn;
     a.split = use_split(ld);
     // the Q heads' input-side backward as two shared-operand GEMMs on the bf16 pipe (qbwd2_kernels.h) where it applies
     a.q_de_slots = d.n_heads;
@@ -932,13 +934,15 @@ extern "C" int prism_act_forward(const prism_learner_desc *ld, const float *obs,
 
 // IDSActionSelector.generate_action_probs + select_action without random sampling (action_selectors.py:125-176).
 extern "C" int prism_ids_select(const float *z, const float *q, int32_t n, int32_t n_pad, int32_t n_tau, int32_t n_actions,
-                                int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, float *out_scores,
-                                float *out_aux, int64_t *out_action, int64_t *out_action_host, prism_stream_t stream_) {
+                                int32_t n_heads, float lmbda, float epsilon, float rho_lower_bound, int32_t unsquish_fn,
+                                float *out_scores, float *out_aux, int64_t *out_action, int64_t *out_action_host,
+                                prism_stream_t stream_) {
     PRISM_CHECK_ARG(z && q && out_scores && out_action, "null buffers");
+    PRISM_CHECK_ARG(unsquish_fn >= PRISM_SQUISH_NONE && unsquish_fn <= PRISM_SQUISH_SYMLOG, "unknown unsquish function");
     PRISM_CHECK_ARG(n >= 1 && n_pad >= n && n_tau >= 1 && n_actions >= 1 && n_actions <= 16 && n_heads >= 1, "bad sizes");
     const int stage = n_tau * n_actions <= ACT_STAGE_MAX_FLOATS;
     IdsArgs k{z, q, n, n_pad, n_tau, n_actions, n_heads, lmbda, epsilon, rho_lower_bound, out_scores, out_aux, out_action,
-              out_action_host, stage};
+              out_action_host, stage, unsquish_fn};
     hipLaunchKernelGGL(ids_score_kernel, dim3(n), dim3(ACT_THREADS), stage ? (size_t)n_tau * n_actions * 4 : 0, (hipStream_t)stream_, k);
     PRISM_CHECK_LAUNCH();
     return PRISM_OK;

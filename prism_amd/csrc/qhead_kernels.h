@@ -168,7 +168,7 @@ __device__ __forceinline__ void qh_loss_body(const IqnArgs &a, const int b) {
             }
         }
         const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        const float y = a.reward[b] + s_zt[tid * A + best] * dg;
+        const float y = td_target(a.squish, a.reward[b], s_zt[tid * A + best], dg);      // (q_ensemble.py:77-82)
         const float diff = s_zc[tid * A + act] - y;
         s_sq[tid] = diff * diff;
         s_dq[tid] = (wb / (float)B) * a.q_w * (2.0f / (float)Hd) * diff;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(IqnArgs a) {
                 best = aa;
             }
         const float dg = a.gamma[b] * (a.nonterminal[b] ? 1.0f : 0.0f);
-        const float y = a.reward[b] + qtg[best] * dg;
+        const float y = td_target(a.squish, a.reward[b], qtg[best], dg);
         const float diff = s_q[act] - y;
         const float wb = a.per_weights ? a.per_weights[b] : 1.0f;
         const float ql = a.q_w * (diff * diff);

@@ -19,9 +19,11 @@ def build_agent(config, obs_shape, n_actions, process_group=None):
 
     eval_selector = action_selectors.GreedyActionSelector()
     if config.use_ids:
+        from prism_amd.agents import squish_functions
+        _, unsquish = squish_functions.parse(config.loss_squish_fn_id)          # (agent_factory.py:20-27)
         selector = action_selectors.IDSActionSelector(config.ids_lambda, config.ids_use_random_samples,
                                                       config.ids_epsilon, config.ids_rho_lower_bound,
-                                                      config.ids_beta, None)
+                                                      config.ids_beta, unsquish)
     elif config.use_e_greedy:
         selector = action_selectors.EGreedyActionSelector(config.e_greedy_initial_epsilon,
                                                           config.e_greedy_final_epsilon,

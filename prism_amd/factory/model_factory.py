@@ -26,9 +26,6 @@ def check_supported(config):
         bad.append("embedding_model_type=%r (only 'minatar_cnn')" % config.embedding_model_type)
     if config.embedding_model_act_fn_id != "relu":
         bad.append("embedding_model_act_fn_id != 'relu'")
-    if config.loss_squish_fn_id in ("obs_look_further", "symlog"):       # anything else parses to no squish (model_factory.py:16-23)
-        bad.append("loss_squish_fn_id=%r (squish hooks iqn_model.py:141-148 / q_ensemble.py:77-82 "
-                   "are not implemented)" % config.loss_squish_fn_id)
     if config.sparse_init_p != 0.0:
         bad.append("sparse_init_p != 0")
     if config.frame_stack_size != 1:

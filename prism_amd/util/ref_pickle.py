@@ -15,6 +15,11 @@ _OURS = "prism_amd.agents.action_selectors"
 _MAP = {("prism.agents.action_selectors", n): (_OURS, n)
         for n in ("ActionSelector", "GreedyActionSelector", "EGreedyActionSelector", "IDSActionSelector")}
 _MAP[("prism.util.annealing_strategies", "LinearAnneal")] = (_OURS, "LinearAnneal")
+# the IDS selector keeps its unsquish FUNCTION (action_selectors.py:123): pickled by module path like a class
+_SQ = "prism_amd.agents.squish_functions"
+_SQ_NAMES = ("symlog", "symexp", "obs_look_further_squish_fn", "obs_look_further_squish_fn_inverse")
+for _n in _SQ_NAMES:
+    _MAP[("prism.agents.squish_functions", _n)] = (_SQ, _n)
 
 
 # What a ``state.pkl`` legitimately names besides the selector classes: the NumPy generator of the epsilon-greedy
@@ -35,7 +40,8 @@ _ALLOWED = {
     # tensors a selector kept for logging (IDSActionSelector.loggables, action_selectors.py:178-192) travel as a nested
     # torch.save blob: the outer rebuild function is harmless, the blob is opened with weights_only (_safe_storage)
     ("torch._utils", "_rebuild_tensor_v2"),
-} | {(_OURS, n) for n in ("ActionSelector", "GreedyActionSelector", "EGreedyActionSelector", "IDSActionSelector", "LinearAnneal")}
+} | {(_OURS, n) for n in ("ActionSelector", "GreedyActionSelector", "EGreedyActionSelector", "IDSActionSelector", "LinearAnneal")} \
+  | {(_SQ, n) for n in _SQ_NAMES}
 
 
 def _safe_storage(b):
@@ -91,6 +97,11 @@ class _RefPickler(pickle._Pickler):
             self.memoize(obj)
             return
         super().save_global(obj, name)
+
+    # (plain functions reach save_global through the dispatch TABLE, which holds the base class's method: rebind it, or
+    # the selector's unsquish function would be written under this package's path)
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[type(_safe_storage)] = save_global
 
 
 def dumps(obj):

@@ -12,7 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 UPDATE_CASES = ["iqn_small", "iqn_c3", "dqn_c2", "dqn_ln", "dqn_target_c2", "full_c4", "full_small",
                 "full_notarget", "full_doubleq", "iqn_target", "iqn_doubleq", "iqn_tau32",
                 # the reference's ablation presets and the stages its experiment files derive from them
-                "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub"]
+                "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub",
+                # value squish of the TD target (loss_squish_fn_id): symlog / obs_look_further
+                "iqn_symlog", "full_olf", "dqn_symlog"]
 
 
 def load_case(name):
@@ -62,6 +64,7 @@ def spec_from_config(cfg, C=4, A=6):
                      n_basis=cfg.iqn_n_basis_elements, iqn_layers=cfg.iqn_quantile_model_layers,
                      n_tau=cfg.iqn_n_current_state_quantile_samples,
                      n_tau_next=cfg.iqn_n_next_state_quantile_samples, huber_k=cfg.iqn_huber_loss_kappa,
+                     squish=str(cfg.loss_squish_fn_id),
                      dist_loss_weight=cfg.distributional_loss_weight, propagate_grad=propagate,
                      n_heads=heads, head_layers=hl, q_loss_weight=cfg.q_loss_weight, theil_coef=coef,
                      double_q=cfg.use_double_q_learning, max_grad_norm=cfg.max_grad_norm,

@@ -42,11 +42,11 @@ def test_struct_layouts_match_header():
     """ctypes mirrors must have the C sizes (guards against silent field drift)."""
     from prism_amd import _native as N
     assert ctypes.sizeof(N.ReplayDesc) == 8 + 8 + 4 + 4 + 10 * 8 + 16 * 8
-    assert ctypes.sizeof(N.ModelDims) == 16 * 4 + 4 * 4
+    assert ctypes.sizeof(N.ModelDims) == 16 * 4 + 4 * 4 + 4          # (+ squish_fn)
     assert ctypes.sizeof(N.ParamOffsets) == 23 * 8
     assert ctypes.sizeof(N.AdamHyper) == 4 * 8 + 2 * 4
-    # learner desc: dims(80) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40), host_status
-    assert ctypes.sizeof(N.LearnerDesc) == 80 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 8 + 7 * 8 + 8 + 40 + 8
+    # learner desc: dims(84 + 4 padding) off(184) batch+embed(8) 6 ptrs, 7 ptrs, 4 ptrs, seed/offset/rng (24), 6 ptrs + size_t + hyper(40), host_status
+    assert ctypes.sizeof(N.LearnerDesc) == 88 + 184 + 8 + 6 * 8 + 7 * 8 + 4 * 8 + 24 + 24 + 8 + 8 + 7 * 8 + 8 + 40 + 8
     assert ctypes.sizeof(N.DirectDesc) == 8 + 8 * 8 + 8 * 8 + 8 + 8 + 8 + 8
 
 

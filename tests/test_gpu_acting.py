@@ -82,8 +82,10 @@ def test_acting_matches_reference(dev, name, gemm_mode):
         scores = torch.empty((n, A), device=dev)
         aux = torch.empty((n, 4, A), device=dev)
         action = torch.empty(n, dtype=torch.int64, device=dev)
+        from prism_amd.agents.squish_functions import SQUISH_IDS
         N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, cfg.ids_n_q_heads, cfg.ids_lambda,
-                                         cfg.ids_epsilon, cfg.ids_rho_lower_bound, N.ptr(scores), N.ptr(aux), N.ptr(action),
+                                         cfg.ids_epsilon, cfg.ids_rho_lower_bound, SQUISH_IDS.get(str(cfg.loss_squish_fn_id), 0),
+                                         N.ptr(scores), N.ptr(aux), N.ptr(action),
                                          None, N.current_stream_handle()), "prism_ids_select")
         torch.cuda.synchronize()
         np.testing.assert_array_equal(action.cpu().numpy(), ref["action"])
@@ -145,7 +147,7 @@ def test_ids_select_against_oracle_on_random_estimates(dev):
         qb = qb.to(dev)
         scores = torch.empty((n, A), device=dev)
         action = torch.empty(n, dtype=torch.int64, device=dev)
-        N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, heads, 0.1, 1e-10, 0.25, N.ptr(scores), None,
+        N.check(N.lib().prism_ids_select(N.ptr(z), N.ptr(qb), n, n_pad, T, A, heads, 0.1, 1e-10, 0.25, 0, N.ptr(scores), None,
                                          N.ptr(action), None, N.current_stream_handle()), "prism_ids_select")
         torch.cuda.synchronize()
         if T == 1 or heads == 1:

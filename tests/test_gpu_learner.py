@@ -48,7 +48,9 @@ IQN_CASES = ["iqn_small", "iqn_c3", "iqn_tau32", "iqn_target", "iqn_doubleq",
              "full_small", "full_notarget", "full_doubleq", "full_c4",
              "dqn_c2", "dqn_ln", "dqn_target_c2",
              # the reference's ablation presets / experiment stages: width 256, T = 32, LayerNorm off or on
-             "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub"]
+             "abl_iqn", "abl_ln_notarget", "abl_doubleq", "abl_ids", "abl_ids_var", "abl_sub",
+             # value squish of the TD target (loss_squish_fn_id: symlog, obs_look_further) in every loss kernel that forms one
+             "iqn_symlog", "full_olf", "dqn_symlog"]
 
 
 # Both ways of multiplying the forward GEMMs (include/prism_hip.h gemm_mode) are held to the same fixtures at the same

@@ -55,7 +55,9 @@ def test_oracle_matches_reference_update(name):
     if dist is not None:
         np.testing.assert_allclose(dist.numpy(), ref["dist"], rtol=0, atol=LOSS_TOL)
     if cfg.use_ids:
-        r = ids_scores(dist, q, cfg.ids_lambda, cfg.ids_epsilon, cfg.ids_rho_lower_bound)
+        from oracle.learner_ref import squish_pair
+        r = ids_scores(dist, q, cfg.ids_lambda, cfg.ids_epsilon, cfg.ids_rho_lower_bound,
+                       squish_pair(H.spec_from_config(cfg, C=int(g["C"]), A=int(g["A"])))[1])
         np.testing.assert_allclose(r["scores"].numpy(), ref["ids/IDS Scores"], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(r["var_z"].numpy(), ref["ids/Return Distribution Variance"], rtol=1e-3, atol=1e-7)
         np.testing.assert_array_equal(r["action"].numpy(), ref["action"])

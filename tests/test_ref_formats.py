@@ -58,6 +58,23 @@ def test_state_pkl_written_here_names_the_reference_classes():
     assert set(vars(ref_ids)) == set(vars(state["ids"]))
 
 
+def test_selector_unsquish_function_travels_by_the_reference_path():
+    """An IDS selector built with a value squish keeps its unsquish FUNCTION (agent_factory.py:20-27); pickle writes a
+    function by module path, so the file must name the reference's module and load back as the local function."""
+    import torch
+    from prism_amd.agents import action_selectors as S, squish_functions as Q
+    from prism_amd.util import ref_pickle
+    for sid, fn in (("symlog", Q.symexp), ("obs_look_further", Q.obs_look_further_squish_fn_inverse)):
+        squish, unsquish = Q.parse(sid)
+        assert unsquish is fn and Q.unsquish_id(unsquish) == Q.SQUISH_IDS[sid]
+        x = torch.linspace(-7.0, 9.0, 33)
+        torch.testing.assert_close(unsquish(squish(x)), x, rtol=2e-5, atol=2e-5)          # a pair of inverses
+        data = ref_pickle.dumps({"action_selector": S.IDSActionSelector(0.1, False, 1e-10, 0.25, 0.8, unsquish)})
+        assert b"prism_amd" not in data and b"cprism.agents.squish_functions\n" + fn.__name__.encode() + b"\n" in data
+        assert ref_pickle.loads(data)["action_selector"].unsquish_function is fn
+    assert Q.parse("none") == (None, None) and Q.parse("anything else") == (None, None) and Q.unsquish_id(None) == 0
+
+
 def check_next_obs(next_obs, ring, recs, exp):
     """Next observations of the sampleable rows vs the reference's own post-load collate.  One artefact of the
     reference's load is NOT reproduced: a kept timestep whose cached ``n_step_next`` names a timestep the load left

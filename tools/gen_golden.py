@@ -106,6 +106,12 @@ CASES = {
                     64, 2, False),
     "abl_sub": (dict(base="subtractive", use_layer_norm=True, use_per=False, use_target_network=True,
                      target_update_period=4_000), 64, 2, False),
+    # ---- the value-squish hooks of the TD target (loss_squish_fn_id; model_factory.py:16-23, iqn_model.py:141-148,
+    # q_ensemble.py:77-82; the IDS selector scores unsquished estimates, action_selectors.py:128-130)
+    "iqn_symlog": (dict(use_ids=False, use_iqn=True, use_dqn=False, loss_squish_fn_id="symlog"), 32, 2, False),
+    "full_olf": (dict(use_ids=True, use_iqn=True, use_target_network=True, loss_squish_fn_id="obs_look_further"), 16, 2, False),
+    "dqn_symlog": (dict(use_ids=False, use_iqn=False, use_dqn=True, use_layer_norm=False, loss_squish_fn_id="symlog"),
+                   32, 2, False),
 }
 
 
