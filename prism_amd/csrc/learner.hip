@@ -784,7 +784,8 @@ extern "C" int prism_learner_fwd_bwd(const prism_learner_desc *ld, prism_stream_
             constexpr int HH = decltype(h)::value;
             constexpr bool LL = decltype(l)::value;
             const size_t lds = qb_lds_floats(HH) * sizeof(float);
-            if (B <= 128) {      // small batches: a wave per column slice over all rows (qhead_kernels.h, COLS)
+            static const bool cols_off = [] { const char *e = getenv("PRISM_QB_COLS"); return e && atoi(e) == 0; }();      // (A/B runs)
+            if (B <= 128 && !cols_off) {      // small batches: a wave per column slice over all rows (qhead_kernels.h, COLS)
                 herr = set_max_lds((const void *)qh_bwd_kernel<HH, LL, true>, lds);
                 if (herr == hipSuccess)
                     hipLaunchKernelGGL((qh_bwd_kernel<HH, LL, true>), dim3((E_DIM / 64) * ld->dims.n_heads), dim3(256), lds, stream, a);

@@ -856,6 +856,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     float sq = 0.f;
     float4 g_own = make_float4(0.f, 0.f, 0.f, 0.f);     // (fused tail) the slab sum of this thread, kept for its Adam update
     bool far_all = false;       // every store of this role that another workgroup reads behind the barrier was a far_store
+    int norm_slot = bid;        // where this workgroup's sum of squared gradients goes (-1: it has none to report)
     if (dqn1 && blk < n_conv) {
         // fold the per-sample rows of the loss kernel: 64 outputs x 16 batch parts per workgroup
         float *s_part = reinterpret_cast<float *>(s_pool);           // [16][CONV_FOLD_W]
@@ -933,6 +934,13 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         }
         __syncthreads();
         PRISM_STAMP(21);
+        // The conv gradient's squares are summed by WHICHEVER workgroup arrived last: reported in that workgroup's own slot they
+        // moved from slot to slot between runs, and with them the order in which the partial norms are added -- the global norm
+        // (and, once it clips, every parameter) differed in the last bit from one run of the same seed to the next (found by
+        // tools/soak.py twin: two learners of one seed side by side).  They always go to the role's FIRST slot, which nobody
+        // else writes; every other conv slot gets its workgroup's zero.
+        norm_slot = s_last ? 0 : (bid == 0 ? -1 : bid);
+        if (s_last && bid != 0 && tid == 0) __hip_atomic_store(a.ws.normpart + bid, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_last) {
             // fold all partial rows: item = (output, half of the rows), combined through LDS
             const int nk = 9 * C, n_out = 16 * nk + 16;
@@ -1068,7 +1076,7 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
     }
     const float t = block_sum_1024(sq, s_red);
     // (agent scope: written through to where the other XCDs' agent-scope loads look for it, whatever release follows)
-    if (tid == 0) __hip_atomic_store(a.ws.normpart + bid, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && norm_slot >= 0) __hip_atomic_store(a.ws.normpart + norm_slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bid == 0 && tid == 0 && a.has_target) a.ws.ticket[2] = 1u;      // the front / embed launch of this update packed the target set
     PRISM_STAMP(14);
     if constexpr (TAIL) {
