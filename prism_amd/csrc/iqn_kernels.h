@@ -1100,6 +1100,12 @@ __global__ __launch_bounds__(256, (H == 128 && !DB) ? 2 : 1) void iqn_bwd_kernel
 constexpr int CONV_ROW = 16 * 90 + 16;   // floats per partial row: 16 * 9C weights (C <= 10) + 16 biases
 constexpr int SMALL_MAX_B = 4096;
 
+// A gradient element another workgroup of the SAME launch reads behind the fused tail's grid barrier: stored at agent
+// scope (written through, past this XCD's L2), so that the producer's barrier arrival needs no L2 write-back -- it only
+// waits for these stores.  The reader uses agent-scope loads (tail_clip_adam).
+__device__ __forceinline__ void far_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float far_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // d conv_w / d conv_b partial sums over the samples of block cb, all 16 output channels, on the matrix core.
 // (minatar_cnn_model.py:43-46 backward: dW[c][k] = sum_b sum_pos dconv[b][c][pos] * patch[b][pos][k], k = (ci, dy, dx);
 // db[c] = sum_b sum_pos dconv[b][c][pos].)  That is a [16 x 64 B] x [64 B x 9C] product: per sample sixteen K steps (four
@@ -1208,15 +1214,12 @@ __device__ __forceinline__ void conv_bwd_partial_block(const IqnArgs &a, int cb,
         const int c = 4 * (ln >> 4) + r, k = 16 * tn + (ln & 15);
         float t = 0.f;
         for (int q = 0; q < G; ++q) t += lds[(q * NT + tn) * 256 + e];
-        if (k < K) out[c * K + k] = t;
-        else if (k == K) out[16 * K + c] = t;
+        // (written through: the workgroup that folds the rows -- the last to arrive -- reads them at agent scope, step_kernels.h)
+        if (k < K) far_store(&out[c * K + k], t);
+        else if (k == K) far_store(&out[16 * K + c], t);
     }
 }
 
-// A gradient element another workgroup of the SAME launch reads behind the fused tail's grid barrier: stored at agent
-// scope (written through, past this XCD's L2), so that the producer's barrier arrival needs no L2 write-back -- it only
-// waits for these stores.  The reader uses agent-scope loads (tail_clip_adam).
-__device__ __forceinline__ void far_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // b1, LN2 affine, W2, b2 gradients of one [LN -> Linear(H -> A)] head for the 16 hidden units
 // [slice*16, slice*16+16), shared by the IQN head and the Q-ensemble heads:

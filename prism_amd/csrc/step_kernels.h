@@ -921,17 +921,12 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
         // CDNA guide): EVERY storing wave drains its stores (a barrier alone only proves they were issued),
         // the workgroup barrier, then ONE lane releases (L2 write-back), waits again (hipcc may drop the fence's
         // own wait) and draws the ticket; the last arriver acquires before any of its waves reads
+        // (round 4: the rows are written THROUGH (far_store) and the last arriver reads them at agent scope: no release fence
+        // -- an L2 write-back: 3.6 us between "partial rows out" and the ticket by the stamps of the additive ablation preset,
+        // whose fused tail waits for exactly this role -- and no acquire on the other side)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_last = (atomicAdd(a.ws.ticket + 1, 1u) == (unsigned)(n_conv - 1));
-            if (s_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
+        if (tid == 0) s_last = (atomicAdd(a.ws.ticket + 1, 1u) == (unsigned)(n_conv - 1));
         __syncthreads();
         PRISM_STAMP(21);
         // The conv gradient's squares are summed by WHICHEVER workgroup arrived last: reported in that workgroup's own slot they
@@ -952,20 +947,21 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
                 if (o < n_out) {
                     const int r0 = half * hrows, r1 = min(n_conv, r0 + hrows);
 #pragma unroll 16
-                    for (int ch = r0; ch < r1; ++ch) s += a.ws.convpart[(int64_t)ch * CONV_ROW + o];
+                    for (int ch = r0; ch < r1; ++ch) s += far_load(&a.ws.convpart[(int64_t)ch * CONV_ROW + o]);
                 }
                 __syncthreads();
                 s_half[tid] = s;
                 __syncthreads();
                 if (half == 0 && o < n_out) {
                     const float t = s_half[tid] + s_half[tid + 512];
-                    if (o < 16 * nk) a.grads[a.off.conv_w + o] = t;
-                    else a.grads[a.off.conv_b + (o - 16 * nk)] = t;
+                    if (o < 16 * nk) far_store(&a.grads[a.off.conv_w + o], t);
+                    else far_store(&a.grads[a.off.conv_b + (o - 16 * nk)], t);
                     sq += t * t;
                 }
             }
             if (tid == 0) a.ws.ticket[1] = 0u;
         }
+        far_all = true;        // (every store of this role another workgroup reads was written through)
     } else {
         blk -= n_conv;
         bool done = false;

@@ -127,24 +127,31 @@ def test_kernels_use_no_scratch_memory(device_isa):
 def test_release_tickets_drain_every_wave_first(device_isa):
     """Cross-workgroup hand-offs (the conv-partial ticket, the grid barrier of the fused tail) publish data other
     workgroups read once the ticket says so.  The protocol: EVERY wave drains its own stores (s_waitcnt vmcnt(0)), the
-    workgroup meets (s_barrier), then one lane writes the L2 back (buffer_wbl2) and draws the ticket (a returning
-    global_atomic_add).  A barrier alone only proves the stores were issued; hipcc moves or drops the wait unless it is
-    pinned.  Check the emitted ISA: walking back from every release ticket, the last s_waitcnt before its s_barrier
-    waits for vmcnt(0), with no store in between."""
+    workgroup meets (s_barrier), then one lane draws the ticket (a returning global_atomic_add) -- after writing the L2 back
+    (buffer_wbl2) where the data went out through ordinary stores, without where every store was written through (far_store:
+    the conv ticket since round 4, the light arrivals of the grid barrier).  A barrier alone only proves the stores were
+    issued; hipcc moves or drops the wait unless it is pinned.  Check the emitted ISA: walking back from every ticket that
+    has a workgroup barrier in front of it, the last s_waitcnt before that s_barrier waits for vmcnt(0), with no store in
+    between."""
     text = device_isa["learner.hip"]
     lines = text.splitlines()
     tickets = [i for i, l in enumerate(lines) if re.search(r"\bglobal_atomic_add(_x2)?\b.*\bsc0\b", l)]
-    checked, bad = 0, []
+    checked, released, bad = 0, 0, []
     for i in tickets:
-        # release ticket? (a write-back between the atomic and the barrier in front of it)
         j, wb = i - 1, False
         while j >= 0 and "s_barrier" not in lines[j] and not re.match(r"^\S+:\s*$", lines[j].split(";")[0]) or \
                 (j >= 0 and lines[j].startswith(".LBB")):
             wb = wb or "buffer_wbl2" in lines[j]
             j -= 1
-        if not wb or j < 0 or "s_barrier" not in lines[j]:
-            continue          # a plain counter (e.g. "last workgroup advances the step count"): nothing is handed over
+        if j < 0 or "s_barrier" not in lines[j]:
+            continue          # no workgroup barrier in front of it: a lane's own counter, nothing of the other waves is handed over
+        f = i
+        while f > 0 and not re.match(r"^_ZN\S+:", lines[f]):
+            f -= 1
+        if not wb and "iqn_post_kernel" not in lines[f]:
+            continue          # a plain counter outside the post launch ("last workgroup advances the step count"): nothing is handed over
         checked += 1
+        released += int(wb)
         k, ok = j - 1, False
         while k >= 0:                     # back from the barrier: a vmcnt(0) wait before any memory instruction or label
             ins = lines[k].split(";")[0].strip()
@@ -156,5 +163,6 @@ def test_release_tickets_drain_every_wave_first(device_isa):
             k -= 1
         if not ok:
             bad.append((i + 1, lines[i].strip()))
-    assert checked >= 7, f"expected the conv tickets of five post-kernel forms and two grid barriers, found {checked}"
+    assert released >= 2, f"expected the full-release arrivals of the two fused-tail instantiations, found {released}"
+    assert checked >= 7, f"expected the conv tickets of five post-kernel forms and the grid barriers, found {checked}"
     assert not bad, f"release tickets whose workgroup barrier is not preceded by a vmcnt(0) drain: {bad}"
