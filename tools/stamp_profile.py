@@ -146,10 +146,13 @@ if os.environ.get("STAMP_ROLES"):
     lo_ = 0
     allrows = np.arange(0, sum(int(p_.split(":")[1]) for p_ in os.environ["STAMP_ROLES"].split(",")))
     t0r = s[allrows, 32 + 13].astype(np.float64).min()
+    _rot, _nb = int(os.environ.get("STAMP_ROT", "0")), len(allrows)
     print("   role            n   start med/max us   role end med/max us   past barrier med/max us   end med/max us")
     for part in os.environ["STAMP_ROLES"].split(","):
         nm, cnt = part.split(":"); cnt = int(cnt)
         rows = np.arange(lo_, lo_ + cnt); lo_ += cnt
+        if _rot:      # (split form: the launch's first STAMP_ROT workgroups take the LAST roles, step_kernels.h) role -> workgroup index
+            rows = np.where(rows >= _nb - _rot, rows - (_nb - _rot), rows + _rot)
         g_ = lambda k: (s[rows, 32 + k].astype(np.float64) - t0r) / 100.0
         f_ = lambda x: f"{np.median(x):7.2f}/{np.max(x):7.2f}"
         print(f"   {nm:10s} {cnt:4d}   {f_(g_(13))}   {f_(g_(14))}   {f_(g_(25)) if (s[rows, 32 + 25] != 0).any() else '-':>15s}   {f_(g_(9)) if (s[rows, 32 + 9] != 0).any() else '-':>15s}")
