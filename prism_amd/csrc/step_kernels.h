@@ -941,6 +941,23 @@ __global__ __launch_bounds__(1024) void iqn_post_kernel(IqnArgs a, PostWriteback
             const int nk = 9 * C, n_out = 16 * nk + 16;
             float *s_half = reinterpret_cast<float *>(s_pool);
             const int hrows = (n_conv + 1) / 2;
+            if (n_conv <= 16) {
+                // few rows (batch 64: eight): one thread an output, every row requested at once -- one trip, no LDS, no barrier
+                // (as (output, half) items the 592 outputs of C = 4 took two passes of 512: two trips and four barriers on the
+                // path the additive presets' fused tail waits for)
+                for (int o = tid; o < n_out; o += 1024) {               // (up to 1456 outputs at ten channels: two trips there)
+                    float v[16];
+#pragma unroll
+                    for (int ch = 0; ch < 16; ++ch) v[ch] = far_load(&a.ws.convpart[(int64_t)min(ch, n_conv - 1) * CONV_ROW + o]);
+                    float t = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 16; ++ch)
+                        if (ch < n_conv) t += v[ch];
+                    if (o < 16 * nk) far_store(&a.grads[a.off.conv_w + o], t);
+                    else far_store(&a.grads[a.off.conv_b + (o - 16 * nk)], t);
+                    sq += t * t;
+                }
+            } else
             for (int base = 0; base < n_out; base += 512) {
                 const int o = base + (tid & 511), half = tid >> 9;
                 float s = 0.f;
