@@ -107,7 +107,9 @@ fx = s[B:B + 1024, [27, 31]].astype(np.float64)
 fx = fx[fx[:, 0] != 0]
 if len(fx): print(f"front extra blocks (u/v, weight packing): n={len(fx)} dur med {int(np.median(fx[:, 1] - fx[:, 0]))} max {int(np.max(fx[:, 1] - fx[:, 0]))}")
 # post kernel: per-block start/end (slots 13, 14); roles by block index (conv | slab | small | ... | writeback)
-n_conv = 1 if (cfg.use_iqn and not cfg.use_ids and not cfg.use_dqn) else (B + 3) // 4
+# conv role of the post launch: one fold block where the backward kernel produced the partial rows (IQN-only, width 128), else one
+# block per eight samples (C = 4 here: step_kernels.h post_conv_blocks)
+n_conv = 1 if (cfg.use_iqn and not cfg.use_ids and not cfg.use_dqn and cfg.iqn_quantile_model_feature_dim == 128) else (B + 7) // 8
 pb = s[:, 13] != 0
 ps_, pe_ = s[pb, 13].astype(np.float64), s[pb, 14].astype(np.float64)
 idx = np.nonzero(pb)[0]
